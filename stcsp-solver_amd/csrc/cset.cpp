@@ -1,0 +1,473 @@
+// cset.cpp -- see cset.hpp.
+#include "cset.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+
+namespace stcsp {
+
+// constraintNodeHasFirst (reference src/constraint.cpp:240-250)
+static bool tree_has_first(const Tree *t) {
+    if (!t) return false;
+    if (t->token == STCSP_T_FIRST || t->token == STCSP_T_AT) return true;
+    if (t->token == STCSP_T_VAR || t->token == STCSP_T_CONST) return false;
+    return tree_has_first(t->left) || tree_has_first(t->right);
+}
+static bool tree_has_arr(const Tree *t) {
+    if (!t) return false;
+    if (t->token == STCSP_T_ARR) return true;
+    return tree_has_arr(t->left) || tree_has_arr(t->right);
+}
+// constraintVarLinkRe (src/constraint.cpp:201-216): distinct identifiers, first-occurrence order
+static void collect_scope(const Tree *t, std::vector<int> &scope) {
+    if (!t) return;
+    if (t->token == STCSP_T_VAR) {
+        if (std::find(scope.begin(), scope.end(), t->var) == scope.end()) scope.push_back(t->var);
+    } else {
+        collect_scope(t->left, scope);
+        collect_scope(t->right, scope);
+    }
+}
+static void collect_first_vars(const Tree *t, bool under_first, std::set<int> &out) {
+    if (!t) return;
+    if (t->token == STCSP_T_VAR) {
+        if (under_first) out.insert(t->var);
+        return;
+    }
+    bool u = under_first || t->token == STCSP_T_FIRST;
+    collect_first_vars(t->left, u, out);
+    collect_first_vars(t->right, u, out);
+}
+// constraintNodeEq (src/constraint.cpp:551-561): token, num, var and shape
+static bool tree_eq(const Tree *a, const Tree *b) {
+    if (!a && !b) return true;
+    if (!a || !b) return false;
+    if (a->token != b->token || a->num != b->num || a->var != b->var) return false;
+    return tree_eq(a->left, b->left) && tree_eq(a->right, b->right);
+}
+static bool set_eq(const HostSet &a, const HostSet &b) {  // constraintQueueEq (:564-576)
+    if (a.cons.size() != b.cons.size()) return false;
+    for (size_t i = 0; i < a.cons.size(); i++)
+        if (!tree_eq(a.cons[i].root, b.cons[i].root)) return false;
+    return true;
+}
+static void serialise_tree(const Tree *t, std::vector<int32_t> &out) {
+    if (!t) {
+        out.push_back(-1);
+        return;
+    }
+    out.push_back(t->token);
+    out.push_back(t->num);
+    out.push_back(t->var);
+    out.push_back(t->arr);
+    serialise_tree(t->left, out);
+    serialise_tree(t->right, out);
+}
+static Tree *deserialise_tree(const int32_t *&p, const int32_t *end, TreeArena &arena) {
+    if (p >= end) return nullptr;
+    int tok = *p++;
+    if (tok < 0) return nullptr;
+    if (p + 3 > end) return nullptr;
+    int num = *p++, var = *p++, arr = *p++;
+    Tree *l = deserialise_tree(p, end, arena);
+    Tree *r = deserialise_tree(p, end, arena);
+    return arena.make(tok, num, var, arr, l, r);
+}
+
+// solverConstraintQueuePush (src/constraint.cpp:254-318)
+int SetManager::push_constraint(HostSet &s, Tree *root) {
+    HostCon c;
+    c.root = root;
+    if (!root || !is_constraint_root(root->token) || !root->left || !root->right) {
+        error = "constraint root is not a constraint operator";
+        return STCSP_E_INVALID;
+    }
+    if (root->token == STCSP_T_UNTIL_CON) {
+        if (root->left->token != STCSP_T_VAR || root->right->token != STCSP_T_VAR) {
+            error = "until operands must be variables after normalisation";
+            return STCSP_E_INVALID;
+        }
+        c.type = CT_UNTIL;
+        c.x = root->left->var;
+        c.y = root->right->var;
+        if (!is_until[c.y]) {
+            is_until[c.y] = 1;
+            n_until++;
+        }
+        int ord = 0;
+        for (auto &o : s.cons) ord += o.type == CT_UNTIL;
+        c.until_ordinal = ord;
+    } else if (root->right->token == STCSP_T_NEXT) {
+        if (root->left->token != STCSP_T_VAR || !root->right->right || root->right->right->token != STCSP_T_VAR) {
+            error = "next constraint is not of the normalised form X == next Y";
+            return STCSP_E_INVALID;
+        }
+        c.type = CT_NEXT;
+        c.x = root->left->var;
+        c.y = root->right->right->var;
+        if (!is_sig[c.x]) {
+            is_sig[c.x] = 1;
+            n_sig++;
+        }
+    } else if (root->right->token == STCSP_T_AT) {
+        c.type = CT_AT;
+    } else {
+        c.type = CT_POINT;
+    }
+    if (tree_has_first(root)) {
+        has_first = true;
+        c.has_first = true;
+    }
+    collect_scope(root, c.scope);
+    s.cons.push_back(c);
+    return STCSP_OK;
+}
+
+void SetManager::finish_set(HostSet &s) {
+    std::set<int> fv;
+    bool any_first_or_at = false;
+    for (auto &c : s.cons) {
+        collect_first_vars(c.root, false, fv);
+        any_first_or_at |= tree_has_first(c.root);
+    }
+    s.first_vars.assign(fv.begin(), fv.end());
+    s.self_loop = !any_first_or_at;
+}
+
+int SetManager::register_set(std::unique_ptr<HostSet> s) {
+    finish_set(*s);
+    int idx = (int)sets.size();
+    if (sharded) {
+        std::vector<int32_t> words;
+        for (auto &c : s->cons) serialise_tree(c.root, words);
+        uint64_t h = 1469598103934665603ull;
+        for (int32_t w : words) {
+            h ^= (uint32_t)w;
+            h *= 1099511628211ull;
+        }
+        int32_t tag = (int32_t)((h ^ (h >> 31)) & 0x3fffffff);
+        if (idx == 0) tag = 0;  // the initial set is set 0 everywhere
+        while (find_tag(tag) >= 0 || (idx != 0 && tag == 0)) tag = (tag + 1) & 0x3fffffff;
+        s->tag = tag;
+    } else {
+        s->tag = idx;
+    }
+    sets.push_back(std::move(s));
+    return idx;
+}
+
+int SetManager::find_tag(int32_t tag) const {
+    for (size_t i = 0; i < sets.size(); i++)
+        if (sets[i]->tag == tag) return (int)i;
+    return -1;
+}
+
+int SetManager::init(const stcsp_problem *p, bool sharded_tags) {
+    if (!p || p->n_vars <= 0 || p->prefix_k <= 0 || !p->var_lb || !p->var_ub || p->n_constraints < 0) {
+        error = "invalid problem descriptor";
+        return STCSP_E_INVALID;
+    }
+    sharded = sharded_tags;
+    N = p->n_vars;
+    K = p->prefix_k;
+    lb.assign(p->var_lb, p->var_lb + N);
+    ub.assign(p->var_ub, p->var_ub + N);
+    for (int v = 0; v < N; v++)
+        if (lb[v] > ub[v]) {
+            error = "variable with empty domain";
+            return STCSP_E_INVALID;
+        }
+    array_off.assign(1, 0);
+    for (int a = 0; a < p->n_arrays; a++) {
+        arrays.elements.emplace_back(p->array_data + p->array_off[a], p->array_data + p->array_off[a + 1]);
+        array_data.insert(array_data.end(), arrays.elements.back().begin(), arrays.elements.back().end());
+        array_off.push_back((int32_t)array_data.size());
+    }
+    is_sig.assign(N, 0);
+    is_until.assign(N, 0);
+    std::unique_ptr<HostSet> s0(new HostSet());
+    for (int c = 0; c < p->n_constraints; c++) {
+        int root = p->constraint_root[c];
+        if (root < 0 || root >= p->n_nodes) {
+            error = "constraint root out of range";
+            return STCSP_E_INVALID;
+        }
+        int rc = push_constraint(*s0, unflatten(p, root, s0->arena));
+        if (rc != STCSP_OK) return rc;
+    }
+    for (auto &c : s0->cons)
+        if (c.type == CT_UNTIL) {
+            n_until_cons++;
+            until_x.push_back(c.x);
+            until_y.push_back(c.y);
+        }
+    for (int v = 0; v < N; v++)
+        if (is_sig[v]) sig_vars.push_back(v);
+    register_set(std::move(s0));
+    if (!has_first) sets[0]->self_loop = true;  // no translation at all (solveralgorithm.cpp:755)
+    return STCSP_OK;
+}
+
+// constraintNodeTranslateFirst (src/constraint.cpp:466-480)
+Tree *SetManager::translate_first(HostSet &dst, const Tree *t, const std::map<int, int> &vals) {
+    if (!t) return nullptr;
+    if (t->token == STCSP_T_VAR) return dst.arena.constant(vals.at(t->var));
+    Tree *l = translate_first(dst, t->left, vals);
+    Tree *r = translate_first(dst, t->right, vals);
+    return dst.arena.make(t->token, t->num, -1, t->arr, l, r);
+}
+// constraintNodeTranslate (src/constraint.cpp:509-537)
+Tree *SetManager::translate(HostSet &dst, const Tree *t, const std::map<int, int> &vals) {
+    if (!t) return nullptr;
+    if (t->token == STCSP_T_FIRST) {
+        Tree *sub = translate_first(dst, t->right, vals);
+        Lifted v = fold(sub, arrays);
+        return v.unknown ? sub : dst.arena.constant(v.value);
+    }
+    if (t->token == STCSP_T_EQ_CON && t->right && t->right->token == STCSP_T_AT) {
+        // constraintNodeTranslateAT (:484-505)
+        int x = t->left->var, y = t->right->left->var, k = t->right->right->num;
+        Tree *r = (k == 1) ? dst.arena.make(STCSP_T_FIRST, 0, -1, -1, nullptr, dst.arena.variable(y))
+                           : dst.arena.make(STCSP_T_AT, 0, -1, -1, dst.arena.variable(y), dst.arena.constant(k - 1));
+        return dst.arena.make(t->token, 0, -1, -1, dst.arena.variable(x), r);
+    }
+    Tree *l = translate(dst, t->left, vals);
+    Tree *r = translate(dst, t->right, vals);
+    return dst.arena.make(t->token, t->num, t->var, t->arr, l, r);
+}
+
+int SetManager::transition(int set, const std::vector<int> &first_vals) {
+    HostSet &s = *sets[set];
+    if (s.self_loop) return set;
+    auto it = s.trans.find(first_vals);
+    if (it != s.trans.end()) return it->second;
+    if (first_vals.size() != s.first_vars.size()) {
+        error = "transition: wrong number of captured values";
+        return STCSP_E_INTERNAL;
+    }
+    std::map<int, int> vals;
+    for (size_t i = 0; i < first_vals.size(); i++) vals[s.first_vars[i]] = first_vals[i];
+    std::unique_ptr<HostSet> ns(new HostSet());
+    std::vector<Tree *> roots;
+    for (auto &c : s.cons) {
+        Tree *t = translate(*ns, c.root, vals);
+        if (!is_tautology(t, arrays)) roots.push_back(t);
+    }
+    for (Tree *t : roots) {
+        int rc = push_constraint(*ns, t);
+        if (rc != STCSP_OK) return rc;
+    }
+    int found = -1;
+    for (size_t i = 0; i < sets.size() && found < 0; i++)
+        if (set_eq(*ns, *sets[i])) found = (int)i;
+    if (found < 0) found = register_set(std::move(ns));
+    sets[set]->trans[first_vals] = found;  // (s may dangle after register_set: re-index)
+    return found;
+}
+
+std::vector<int32_t> SetManager::serialise_set(int set) const {
+    std::vector<int32_t> out;
+    const HostSet &s = *sets[set];
+    out.push_back(s.tag);
+    out.push_back((int32_t)s.cons.size());
+    for (auto &c : s.cons) serialise_tree(c.root, out);
+    return out;
+}
+
+int SetManager::import_set(const int32_t *words, size_t n) {
+    if (n < 2) return STCSP_E_INVALID;
+    int32_t tag = words[0];
+    int found = find_tag(tag);
+    if (found >= 0) return found;
+    int ncons = words[1];
+    const int32_t *p = words + 2, *end = words + n;
+    std::unique_ptr<HostSet> ns(new HostSet());
+    for (int i = 0; i < ncons; i++) {
+        Tree *t = deserialise_tree(p, end, ns->arena);
+        int rc = push_constraint(*ns, t);
+        if (rc != STCSP_OK) return rc;
+    }
+    for (size_t i = 0; i < sets.size(); i++)
+        if (set_eq(*ns, *sets[i])) return (int)i;
+    int idx = register_set(std::move(ns));
+    if (sets[idx]->tag != tag) {
+        error = "constraint-set tag mismatch between shards";
+        return STCSP_E_INTERNAL;
+    }
+    return idx;
+}
+
+// ------------------------------------------------------------------ bytecode compiler
+// Postfix program with the evaluation order of solverValidateRe (reference
+// src/solveralgorithm.cpp:336-424): children before parent, left before right. Short-circuit
+// forms (if / and / or / ->) are evaluated in full and SELECTED afterwards -- lanes of a
+// wavefront run one instruction stream -- so when the tree contains array lookups, guard
+// markers record which sub-programs the reference would really have evaluated: only a LIVE
+// out-of-range lookup clears `valid` (:347-349), and once cleared every later arithmetic /
+// relational node yields 0 (:396-397).
+int SetManager::compile_expr(const Tree *t, const std::vector<int> &scope, bool guards, std::vector<int32_t> &code,
+                             int &depth, int &max_depth, int &mask_depth) {
+    if (!t) {
+        error = "malformed constraint tree";
+        return STCSP_E_INVALID;
+    }
+    auto emit = [&](int op, int arg = 0) { code.push_back((arg << 8) | op); };
+    auto push = [&]() {
+        depth++;
+        if (depth > max_depth) max_depth = depth;
+    };
+    auto guarded = [&](int op_mask, int d, const Tree *sub) -> int {
+        if (guards) {
+            if (++mask_depth > 31) {
+                error = "conditional nesting deeper than 31";
+                return STCSP_E_UNSUPPORTED;
+            }
+            emit(op_mask, d);
+        }
+        int rc = compile_expr(sub, scope, guards, code, depth, max_depth, mask_depth);
+        if (guards) {
+            emit(OP_MASK_POP);
+            mask_depth--;
+        }
+        return rc;
+    };
+    int rc;
+    switch (t->token) {
+        case STCSP_T_CONST:
+            emit(OP_CONST);
+            code.push_back(t->num);
+            push();
+            return STCSP_OK;
+        case STCSP_T_VAR: {
+            auto it = std::find(scope.begin(), scope.end(), t->var);
+            emit(OP_VAR, (int)(it - scope.begin()));
+            push();
+            return STCSP_OK;
+        }
+        case STCSP_T_ARR:
+            if ((rc = compile_expr(t->right, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+            emit(OP_ARR, t->arr);
+            return STCSP_OK;
+        case STCSP_T_ABS:
+        case STCSP_T_NOT:
+            if ((rc = compile_expr(t->right, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+            emit(t->token == STCSP_T_ABS ? OP_ABS : OP_NOT);
+            return STCSP_OK;
+        case STCSP_T_FIRST: return compile_expr(t->right, scope, guards, code, depth, max_depth, mask_depth);  // :364-365
+        case STCSP_T_AT: return compile_expr(t->left, scope, guards, code, depth, max_depth, mask_depth);      // :366-367
+        case STCSP_T_IF: {
+            if (!t->right || t->right->token != STCSP_T_THEN) {
+                error = "if without then/else";
+                return STCSP_E_INVALID;
+            }
+            if ((rc = compile_expr(t->left, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+            if ((rc = guarded(OP_MASK_T, 0, t->right->left))) return rc;
+            if ((rc = guarded(OP_MASK_F, 1, t->right->right))) return rc;
+            emit(OP_SEL_IF);
+            depth -= 2;
+            return STCSP_OK;
+        }
+        case STCSP_T_AND:
+        case STCSP_T_OR:
+        case STCSP_T_IMPLY_CON: {
+            if ((rc = compile_expr(t->left, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+            if ((rc = guarded(t->token == STCSP_T_OR ? OP_MASK_F : OP_MASK_T, 0, t->right))) return rc;
+            emit(t->token == STCSP_T_AND ? OP_SEL_AND : (t->token == STCSP_T_OR ? OP_SEL_OR : OP_SEL_IMPLY));
+            depth -= 1;
+            return STCSP_OK;
+        }
+        default: break;
+    }
+    int op = 0;
+    switch (t->token) {
+        case STCSP_T_ADD: op = OP_ADD; break;
+        case STCSP_T_SUB: op = OP_SUB; break;
+        case STCSP_T_MUL: op = OP_MUL; break;
+        case STCSP_T_DIV: op = OP_DIV; break;
+        case STCSP_T_MOD: op = OP_MOD; break;
+        case STCSP_T_LT_OP: case STCSP_T_LT_CON: op = OP_LT; break;
+        case STCSP_T_GT_OP: case STCSP_T_GT_CON: op = OP_GT; break;
+        case STCSP_T_LE_OP: case STCSP_T_LE_CON: op = OP_LE; break;
+        case STCSP_T_GE_OP: case STCSP_T_GE_CON: op = OP_GE; break;
+        case STCSP_T_EQ_OP: case STCSP_T_EQ_CON: op = OP_EQ; break;
+        case STCSP_T_NE_OP: case STCSP_T_NE_CON: op = OP_NE; break;
+        default:
+            error = "expression token not supported inside a point constraint";
+            return STCSP_E_UNSUPPORTED;
+    }
+    if ((rc = compile_expr(t->left, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+    if ((rc = compile_expr(t->right, scope, guards, code, depth, max_depth, mask_depth))) return rc;
+    emit(op);
+    depth -= 1;
+    return STCSP_OK;
+}
+
+int SetManager::compile(FlatProgram &out) {
+    out = FlatProgram();
+    for (size_t si = 0; si < sets.size(); si++) {
+        HostSet &s = *sets[si];
+        SetDesc sd{};
+        sd.con_begin = (int32_t)out.cons.size();
+        sd.ncons = (int32_t)s.cons.size();
+        sd.cw = (sd.ncons + 31) / 32;
+        if (sd.cw < 1) sd.cw = 1;
+        if (sd.cw > 64) {
+            error = "more than 2048 constraints in one set";
+            return STCSP_E_UNSUPPORTED;
+        }
+        if (sd.cw > out.max_cw) out.max_cw = sd.cw;
+        sd.varcons_off = (int32_t)out.varcons.size();
+        out.varcons.resize(out.varcons.size() + (size_t)N * sd.cw, 0u);
+        sd.self_loop = s.self_loop;
+        sd.nfirst = (int32_t)s.first_vars.size();
+        if (sd.nfirst > 64) {
+            error = "more than 64 variables under `first` in one constraint set";
+            return STCSP_E_UNSUPPORTED;
+        }
+        sd.first_off = (int32_t)out.firstvars.size();
+        out.firstvars.insert(out.firstvars.end(), s.first_vars.begin(), s.first_vars.end());
+        sd.trans_begin = (int32_t)out.trans.size();
+        sd.trans_count = (int32_t)s.trans.size();
+        for (auto &kv : s.trans) {
+            TransDesc td{(int32_t)out.transvals.size(), kv.second};
+            out.transvals.insert(out.transvals.end(), kv.first.begin(), kv.first.end());
+            out.trans.push_back(td);
+        }
+        sd.tag = s.tag;
+        for (size_t ci = 0; ci < s.cons.size(); ci++) {
+            HostCon &c = s.cons[ci];
+            ConDesc cd{};
+            cd.type = c.type;
+            cd.npoints = c.has_first ? 1 : K;
+            cd.scope_off = (int32_t)out.scope.size();
+            cd.scope_len = (int32_t)c.scope.size();
+            if (cd.scope_len > kMaxScope) {
+                error = "constraint over more than 64 variables";
+                return STCSP_E_UNSUPPORTED;
+            }
+            out.scope.insert(out.scope.end(), c.scope.begin(), c.scope.end());
+            cd.x = c.x;
+            cd.y = c.y;
+            cd.until_ordinal = c.until_ordinal;
+            cd.code_off = (int32_t)out.code.size();
+            if (c.type == CT_POINT) {
+                bool guards = tree_has_arr(c.root);
+                cd.uses_valid = guards;
+                int depth = 0, max_depth = 0, mask_depth = 0;
+                int rc = compile_expr(c.root, c.scope, guards, out.code, depth, max_depth, mask_depth);
+                if (rc != STCSP_OK) return rc;
+                out.code.push_back(OP_END);
+                if (max_depth > out.max_stack) out.max_stack = max_depth;
+            }
+            cd.code_len = (int32_t)out.code.size() - cd.code_off;
+            out.cons.push_back(cd);
+            if (c.type != CT_AT)  // AT constraints are never revised (solveralgorithm.cpp:658-662)
+                for (int v : c.scope) out.varcons[sd.varcons_off + (size_t)v * sd.cw + ci / 32] |= 1u << (ci % 32);
+        }
+        out.sets.push_back(sd);
+    }
+    return STCSP_OK;
+}
+
+}  // namespace stcsp

@@ -1,0 +1,86 @@
+// cset.hpp -- host side of the engine: constraint-set registry, per-leaf translation and the
+// compiler from constraint trees to the flat device program (device_types.hpp).
+//
+// Reference behaviour reproduced here (all of it runs per LEAF in the reference; the engine
+// runs it once per distinct (set, captured `first` values) and caches the transition):
+//   src/constraint.cpp:254-318  solverConstraintQueuePush  -- classify NEXT/POINT/UNTIL/AT,
+//                                hasFirst, signature / until variables, scope
+//   src/constraint.cpp:466-548  constraintTranslate & helpers -- `first e` -> constant,
+//                                X == Y@k -> X == Y@(k-1) | X == first Y, drop tautologies
+//   src/constraint.cpp:551-576  constraintQueueEq / constraintNodeEq -- set identity
+//   src/solveralgorithm.cpp:755-805  the per-leaf translation / seenConstraints lookup
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cvalue.hpp"
+#include "device_types.hpp"
+#include "tree.hpp"
+
+namespace stcsp {
+
+struct HostCon {
+    Tree *root = nullptr;
+    int type = CT_POINT;
+    bool has_first = false;
+    std::vector<int> scope;  // first-occurrence order (the reference's arc order)
+    int x = -1, y = -1;
+    int until_ordinal = -1;
+};
+
+struct HostSet {
+    std::vector<HostCon> cons;
+    std::vector<int> first_vars;  // sorted ids of the variables that occur under a `first`
+    bool self_loop = false;
+    int32_t tag = 0;
+    std::map<std::vector<int>, int> trans;  // captured first-var values -> next set index
+    TreeArena arena;
+};
+
+struct FlatProgram {
+    std::vector<SetDesc> sets;
+    std::vector<ConDesc> cons;
+    std::vector<int32_t> scope, code, firstvars, transvals;
+    std::vector<uint32_t> varcons;
+    std::vector<TransDesc> trans;
+    int max_stack = 1;
+    int max_cw = 1;
+};
+
+class SetManager {
+public:
+    int N = 0, K = 2;
+    std::vector<int> lb, ub;
+    ArrayTable arrays;
+    std::vector<int32_t> array_off, array_data;
+    std::vector<uint8_t> is_sig, is_until;
+    int n_sig = 0, n_until = 0, n_until_cons = 0;
+    bool has_first = false;  // Solver::hasFirst (sticky)
+    bool sharded = false;    // tags are content hashes instead of ordinals
+    std::vector<int> sig_vars, until_x, until_y;
+    std::vector<std::unique_ptr<HostSet>> sets;
+    std::string error;
+
+    int init(const stcsp_problem *p, bool sharded_tags);
+    // next set for a leaf of `set` whose first-variables have the given values (in
+    // first_vars order); creates and registers the set / transition when unseen.
+    int transition(int set, const std::vector<int> &first_vals);
+    int compile(FlatProgram &out);
+    int find_tag(int32_t tag) const;
+    // serialised registry exchange for sharded runs (every shard must know every set)
+    std::vector<int32_t> serialise_set(int set) const;
+    int import_set(const int32_t *words, size_t n);
+
+private:
+    int push_constraint(HostSet &s, Tree *root);
+    void finish_set(HostSet &s);
+    int register_set(std::unique_ptr<HostSet> s);
+    Tree *translate(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
+    Tree *translate_first(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
+    int compile_expr(const Tree *t, const std::vector<int> &scope, bool guards, std::vector<int32_t> &code, int &depth,
+                     int &max_depth, int &mask_depth);
+};
+
+}  // namespace stcsp

@@ -1,0 +1,114 @@
+// device_types.hpp -- data layout shared by the host-side constraint-set compiler (cset.cpp)
+// and the HIP kernels (engine.hip). Everything is 32-bit words in HBM.
+//
+// DOMAIN BLOCK of one open search node (the build's replacement for Variable::currLB/currUB,
+// reference src/variable.h:19-20): N*K bitset words, point-major:
+//       word[p * N + v]  bit i  <=>  value (lb[v] + i) is in the domain of v at time point p
+// (|D| <= 32 => one word per (v,p); W = 1).  A node record is a 4-word header + the block:
+//       [0] src state id (low 32)   [1] src state id (high 32: owner rank in sharded mode)
+//       [2] constraint-set index     [3] until-expire bits (Constraint::expire, one per UNTIL)
+//       [4 ...] block
+// padded to a multiple of 4 words (16 B) so lanes can move it with aligned wide accesses.
+#pragma once
+#include <cstdint>
+
+namespace stcsp {
+
+constexpr int kRegions = 32;        // cursor shards per segment (spreads allocation atomics)
+constexpr int kMaxDomRegs = 4;      // N*K <= 64 * kMaxDomRegs words live in VGPRs, lane-striped
+constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revision (2^6 = 64)
+constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
+constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
+constexpr uint32_t kRootTag = 0x7fffffffu;
+
+enum ConType : int32_t { CT_NEXT = 0, CT_POINT = 1, CT_UNTIL = 2, CT_AT = 3 };
+
+// bytecode: one word per instruction, (arg << 8) | op; OP_CONST is followed by its immediate.
+enum Op : int32_t {
+    OP_END = 0,
+    OP_CONST,
+    OP_VAR,   // arg = scope index
+    OP_ARR,   // arg = array id; index on top of stack
+    OP_ABS,
+    OP_NOT,
+    OP_ADD,
+    OP_SUB,
+    OP_MUL,
+    OP_DIV,
+    OP_MOD,
+    OP_LT,
+    OP_GT,
+    OP_LE,
+    OP_GE,
+    OP_EQ,
+    OP_NE,
+    OP_MASK_T,  // arg = stack depth d: open a guarded region, live iff stack[top-d] != 0
+    OP_MASK_F,  //                      ... live iff stack[top-d] == 0
+    OP_MASK_POP,
+    OP_SEL_IF,     // [c a b] -> c ? a : b
+    OP_SEL_AND,    // [a b]   -> a ? b : 0
+    OP_SEL_OR,     // [a b]   -> a ? 1 : b     (raw b, solveralgorithm.cpp:378-384)
+    OP_SEL_IMPLY   // [a b]   -> a == 0 ? 1 : (a <= b)
+};
+
+struct ConDesc {          // one constraint of one constraint set
+    int32_t type;         // ConType
+    int32_t npoints;      // time points to enforce: 1 if the constraint has `first`/@, else K
+    int32_t scope_off;    // into scope[]: variable ids, first-occurrence order
+    int32_t scope_len;
+    int32_t code_off;     // into code[]
+    int32_t code_len;
+    int32_t x, y;         // NEXT: X == next Y ; UNTIL: X until Y
+    int32_t until_ordinal;
+    int32_t uses_valid;   // program contains array lookups => track `valid` + liveness
+    int32_t pad0, pad1;
+};
+
+struct SetDesc {          // one constraint set (entry of Solver::seenConstraints)
+    int32_t con_begin;    // into cons[]
+    int32_t ncons;
+    int32_t varcons_off;  // into varcons[]: [N][cw] bitmask rows, cw = (ncons + 31) / 32
+    int32_t cw;
+    int32_t self_loop;    // translation maps the set to itself whatever the leaf values
+    int32_t nfirst;       // variables whose time-0 value the translation reads
+    int32_t first_off;    // into firstvars[]
+    int32_t trans_begin;  // into trans[]: known (values -> next set) transitions of this set
+    int32_t trans_count;
+    int32_t tag;          // id stored in state keys (ordinal when unsharded, content hash when sharded)
+    int32_t pad0, pad1;
+};
+
+struct TransDesc {
+    int32_t vals_off;     // into transvals[]: nfirst values
+    int32_t next_set;     // set index
+};
+
+#if defined(__HIPCC__)
+#define STCSP_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define STCSP_HD inline
+#endif
+
+// hash of a state key (constraint-set tag, signature words): table slot, slot tag and, in
+// sharded runs, the owner shard = (h >> 40) % world.
+STCSP_HD unsigned long long mix64(unsigned long long h, uint32_t w) {
+    h ^= w;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    return h;
+}
+STCSP_HD unsigned long long mix_final(unsigned long long h) {
+    h *= 0x94D049BB133111EBull;
+    h ^= h >> 32;
+    return h;
+}
+constexpr unsigned long long kHashSeed = 0x9E3779B97F4A7C15ull;
+
+// record strides in words (all multiples of 4)
+STCSP_HD int node_stride(int N, int K) { return (4 + N * K + 3) & ~3; }
+STCSP_HD int cand_stride(int N, int K, int sig_len) { return (4 + sig_len + N + N * K + 3) & ~3; }
+STCSP_HD int edge_stride(int N) { return (4 + N + 3) & ~3; }
+// candidate record: [0,1] src gid  [2] next set tag  [3] expire bits  [4..) signature,
+//                   then N edge-label values, then the N*K time-advanced block
+
+}  // namespace stcsp

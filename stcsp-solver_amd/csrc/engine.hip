@@ -1,0 +1,1561 @@
+// engine.hip -- the MI355X (gfx950) stream-CSP propagation + search engine.
+//
+// Replaces the reference's recursive DFS (src/solveralgorithm.cpp:733-942 solverSolveRe) and its
+// arc-queue propagator (:435-706) by a frontier search resident in HBM:
+//
+//   * every open search-tree node is one immutable record: a 4-word header + the packed domain
+//     bitsets of all N variables at all K look-ahead points (device_types.hpp). There is no
+//     trail (src/util.cpp:94-146): children are new records.
+//   * k_expand: ONE 64-lane wavefront per open node. The domain block lives in VGPRs
+//     (lane-striped, read with v_readlane / ds_bpermute, no LDS round trip), propagation runs
+//     to the fixpoint of generalised arc consistency over the node's constraint set:
+//       - X == next Y arcs (enforceNextConsistency, :544-593): shifted word AND;
+//       - point constraints (enforcePointConsistency / findSupport / validate, :428-539):
+//         lanes enumerate tuples of the scope variables' current domains, evaluate the
+//         constraint's postfix program (the role of solverValidateRe, :336-424), and one
+//         __ballot per 64 tuples feeds per-(variable,value) support masks;
+//       - until constraints (enforceUntilConsistency, :598-614): check only.
+//     Then the node is classified like solverSolveRe does: failed / branch (bisect the first
+//     unbound variable: variableSplitLower/Upper, src/variable.cpp:52-67) / leaf.
+//     A leaf emits a successor CANDIDATE: next constraint-set (per-leaf translation,
+//     :755-805, looked up in a device transition table the host fills on demand), signature
+//     (:812-837), edge label, time-advanced block (variableAdvanceOneTimeStep,
+//     src/variable.cpp:94-108).
+//   * k_commit: one wavefront per candidate does lookup-or-insert of (set, signature) in an
+//     open-addressing hash table in HBM (the role of VertexTable, src/graph.h:64;
+//     vertexTableGetVertex/AddVertex, src/graph.cpp:108-123) with a 64-bit CAS claim,
+//     appends the edge record (edgeNew/vertexAddEdge, src/graph.cpp:33-38,78-89) and, for a
+//     new state, opens its first search node.
+//   * ok/fail bookkeeping (:857-874, 904-909) is the order-independent fixpoint of okfix.hpp,
+//     run on the exported edge log.
+//
+// Integer bit work: no MFMA anywhere. Bounded by wave-level ALU/latency, then HBM.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cset.hpp"
+#include "device_types.hpp"
+#include "okfix.hpp"
+#include "stcsp_engine.h"
+
+using namespace stcsp;
+
+namespace {
+
+constexpr int R = kRegions;
+constexpr int CST = kCursorStride;
+constexpr int kStatSlots = 64;
+constexpr int kStatWords = 8;
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_SPARE };
+constexpr int kMissStride = 66;  // set, nfirst, 64 values
+constexpr uint32_t kPending = 0xffffffffu;
+
+// control block (u32 words; every cursor on its own 64-byte line)
+struct CtlLayout {
+    int out0, cand0, edge0, misc0, words;
+    __host__ __device__ CtlLayout(int world) {
+        out0 = 0;
+        cand0 = R * CST;
+        edge0 = cand0 + world * R * CST;
+        misc0 = edge0 + R * CST;
+        words = misc0 + 8 * CST;
+    }
+};
+enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
+enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
+       ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
+
+struct Ctx {
+    int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
+    const int *var_lb;
+    const uint32_t *var_init;
+    const int *arr_off;
+    const int *arr_data;
+    const int *sig_vars;
+    const int *until_y;
+    const SetDesc *sets;
+    const ConDesc *cons;
+    const int *scope;
+    const int *code;
+    const int *firstvars;
+    const TransDesc *trans;
+    const int *transvals;
+    const uint32_t *varcons;
+    unsigned long long *slots;
+    uint32_t slot_mask;
+    uint32_t *state_keys;
+    uint32_t state_cap;
+    uint32_t *ctl;
+    uint32_t *edges;
+    uint32_t edge_cap;  // records per region
+    int *miss;
+    int miss_cap;
+    unsigned long long *stats;
+};
+
+struct ExpandArgs {
+    const uint32_t *in_base;
+    uint32_t in_cap;
+    uint32_t *out_base;
+    uint32_t out_cap;
+    uint32_t *cand_base;
+    uint32_t cand_cap;
+    int take[R];
+    int count[R];
+};
+
+struct CommitArgs {
+    const uint32_t *cand_base;  // regions of owner == rank (regions != 0) or a contiguous array
+    uint32_t cand_cap;
+    int regions;
+    long long total;  // contiguous mode
+    int cand_cursor_base;  // ctl word index of the owner's cursors (regions mode)
+    uint32_t *out_base;
+    uint32_t out_cap;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// position of the k-th (0-based) set bit of m
+__device__ __forceinline__ int select_kth(uint32_t m, int k) {
+    for (int i = 0; i < k; i++) m &= m - 1;
+    return __ffs((int)m) - 1;
+}
+
+// The node's domain block, lane-striped over DR VGPRs: word idx lives in r[idx >> 6], lane idx & 63.
+template <int DR>
+struct Dom {
+    uint32_t r[DR];
+    __device__ __forceinline__ uint32_t get(int idx) const {  // idx wave-uniform
+        uint32_t v = r[0];
+#pragma unroll
+        for (int q = 1; q < DR; q++)
+            if ((idx >> 6) == q) v = r[q];
+        return rdlane(v, idx & 63);
+    }
+    __device__ __forceinline__ uint32_t gather(int idx) const {  // idx per lane
+        uint32_t out = 0;
+#pragma unroll
+        for (int q = 0; q < DR; q++) {
+            uint32_t t = (uint32_t)__shfl((int)r[q], idx & 63, 64);
+            if ((idx >> 6) == q) out = t;
+        }
+        return out;
+    }
+    __device__ __forceinline__ void set(int idx, uint32_t val, int lane) {  // idx wave-uniform
+#pragma unroll
+        for (int q = 0; q < DR; q++)
+            if ((idx >> 6) == q && lane == (idx & 63)) r[q] = val;
+    }
+};
+
+struct WaveStats {
+    unsigned revs = 0;
+    unsigned long long evals = 0;
+};
+
+// Evaluate one constraint program on this lane's tuple (the role of solverValidateRe,
+// reference src/solveralgorithm.cpp:336-424). varinfo/curval are per-lane registers indexed by
+// scope position: varinfo = 1 + slot for lane-enumerated variables (value in lds_vals), 0 for
+// wave-uniform ones (value in curval).
+__device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uint32_t varinfo, int curval,
+                            const int *lds_vals, int *lds_stk) {
+    int t = 0, sp = 0;
+    bool valid = true;
+    uint32_t dead = 0;
+    for (;;) {
+        int w = rfl(c.code[pc++]);
+        int op = w & 255, arg = w >> 8;
+        switch (op) {
+            case OP_END: return t;
+            case OP_CONST:
+                lds_stk[sp * 64 + lane] = t;
+                sp++;
+                t = rfl(c.code[pc++]);
+                break;
+            case OP_VAR: {
+                lds_stk[sp * 64 + lane] = t;
+                sp++;
+                uint32_t info = rdlane(varinfo, arg);
+                if (info)
+                    t = lds_vals[(info - 1) * 64 + lane];
+                else
+                    t = (int)rdlane((uint32_t)curval, arg);
+                break;
+            }
+            case OP_ARR: {
+                int off = rfl(c.arr_off[arg]), size = rfl(c.arr_off[arg + 1]) - off;
+                bool inr = (unsigned)t < (unsigned)size;
+                if (!inr && dead == 0) valid = false;
+                t = inr ? c.arr_data[off + t] : 0;
+                break;
+            }
+            case OP_ABS: t = t < 0 ? (int)(0u - (unsigned)t) : t; break;
+            case OP_NOT: t = (t == 0); break;
+            case OP_MASK_T:
+            case OP_MASK_F: {
+                int v = arg == 0 ? t : lds_stk[(sp - arg) * 64 + lane];
+                bool live = (op == OP_MASK_T) ? (v != 0) : (v == 0);
+                dead = (dead << 1) | (live ? 0u : 1u);
+                break;
+            }
+            case OP_MASK_POP: dead >>= 1; break;
+            case OP_SEL_IF: {
+                int b = t, a = lds_stk[(sp - 1) * 64 + lane], cnd = lds_stk[(sp - 2) * 64 + lane];
+                sp -= 2;
+                t = cnd ? a : b;
+                break;
+            }
+            case OP_SEL_AND: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = a ? t : 0;
+                break;
+            }
+            case OP_SEL_OR: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = a ? 1 : t;
+                break;
+            }
+            case OP_SEL_IMPLY: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = (a == 0) ? 1 : (a <= t);
+                break;
+            }
+            default: {
+                int b = t, a = lds_stk[--sp * 64 + lane], r = 0;
+                switch (op) {
+                    case OP_ADD: r = (int)((unsigned)a + (unsigned)b); break;
+                    case OP_SUB: r = (int)((unsigned)a - (unsigned)b); break;
+                    case OP_MUL: r = (int)((unsigned)a * (unsigned)b); break;
+                    case OP_DIV: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a / b; break;
+                    case OP_MOD: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a % b; break;
+                    case OP_LT: r = a < b; break;
+                    case OP_GT: r = a > b; break;
+                    case OP_LE: r = a <= b; break;
+                    case OP_GE: r = a >= b; break;
+                    case OP_EQ: r = a == b; break;
+                    case OP_NE: r = a != b; break;
+                    default: break;
+                }
+                t = (uses_valid && !valid) ? 0 : r;
+                break;
+            }
+        }
+    }
+}
+
+// Enforce one point constraint at one time point: afterwards every remaining value of every
+// scope variable has a supporting tuple (generalised arc consistency on this constraint; the
+// reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
+// Returns false when a domain is wiped out. `dirty` rows of changed variables are OR-ed in.
+template <int DR>
+__device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, int ci, int p, Dom<DR> &dom, int lane,
+                             uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
+    const int s = C.scope_len;
+    // per-lane view of scope variable j = lane
+    int var = 0;
+    uint32_t D = 0;
+    if (lane < s) {
+        var = c.scope[C.scope_off + lane];
+        }
+    D = dom.gather(p * c.N + var);
+    if (lane >= s) D = 0;
+    int n = lane < s ? __popc(D) : 1;
+    if (__ballot(lane < s && n == 0)) return false;
+    int vlb = lane < s ? c.var_lb[var] : 0;
+
+    // --- split the scope: up to kMaxLowVars variables whose domain sizes multiply to <= 64 are
+    // enumerated ACROSS LANES (lane index = mixed-radix tuple index); the rest are wave-uniform
+    // per iteration (singletons, or "high" variables stepped by an odometer).
+    uint32_t varinfo = 0;  // lane j: 1 + slot if low
+    int stride = 1;        // lane j: radix stride if low
+    int pairbase = 0;      // lane j: first pair lane of low var j
+    int P = 1, nlow = 0, npairs = 0;
+    unsigned long long highmask = 0;
+    for (int j = 0; j < s; j++) {
+        int nj = (int)rdlane((uint32_t)n, j);
+        if (nj <= 1) continue;
+        if (nlow < kMaxLowVars && P * nj <= 64) {
+            if (lane == j) {
+                varinfo = 1 + nlow;
+                stride = P;
+                pairbase = npairs;
+            }
+            nlow++;
+            P *= nj;
+            npairs += nj;
+        } else {
+            highmask |= 1ull << j;
+        }
+    }
+    const bool active = lane < P;
+    // per-lane values of the low variables -> LDS (read back only by the same lane)
+    // and the 64-bit lane masks M[pair] = lanes whose digit of that variable equals k
+    uint32_t Mlo = 0, Mhi = 0;
+    {
+        unsigned long long lowmask = __ballot(varinfo != 0);
+        while (lowmask) {
+            int j = __ffsll((long long)lowmask) - 1;
+            lowmask &= lowmask - 1;
+            int slot = (int)rdlane(varinfo, j) - 1;
+            int st = (int)rdlane((uint32_t)stride, j);
+            int nj = (int)rdlane((uint32_t)n, j);
+            uint32_t Dj = rdlane(D, j);
+            int lbj = (int)rdlane((uint32_t)vlb, j);
+            int pb = (int)rdlane((uint32_t)pairbase, j);
+            int digit = (lane / st) % nj;
+            lds_vals[slot * 64 + lane] = lbj + select_kth(Dj, digit);
+            for (int k = 0; k < nj; k++) {
+                unsigned long long m = __ballot(active && digit == k);
+                if (lane == pb + k) {
+                    Mlo = (uint32_t)m;
+                    Mhi = (uint32_t)(m >> 32);
+                }
+            }
+        }
+    }
+    const bool pairlane = lane < npairs;
+    bool hit = false;       // pair lanes: this (low var, digit) has a support
+    uint32_t hs = 0;        // scope lanes (uniform vars): supported value bits
+    int digit_h = 0;        // scope lanes (high vars): odometer digit
+    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;
+    int curval = vlb + curbit;
+    const bool is_uniform = lane < s && varinfo == 0;
+    const bool is_high = (highmask >> lane) & 1ull;
+    int maxn = 1;
+    {
+        unsigned long long hm = highmask;
+        while (hm) {
+            int j = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            int nj = (int)rdlane((uint32_t)n, j);
+            if (nj > maxn) maxn = nj;
+        }
+    }
+    ws.revs++;
+    const unsigned nact = (unsigned)min(P, 64);
+    // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
+    // value of every high variable appears once, so loose constraints finish here.
+    // stage B: exhaustive odometer over the high variables, early exit once all is supported.
+    bool done = false;
+    unsigned long long iters = 0;
+    int stage_a_left = highmask ? maxn : 1;
+    bool stage_b = false;
+    while (!done) {
+        if (stage_a_left > 0) {
+            if (is_high) {
+                int it = maxn - stage_a_left;
+                curbit = select_kth(D, it % n);
+                curval = vlb + curbit;
+            }
+            stage_a_left--;
+        } else if (!stage_b) {
+            stage_b = true;  // first exhaustive tuple block: all high digits 0
+            if (is_high) {
+                digit_h = 0;
+                curbit = __ffs((int)D) - 1;
+                curval = vlb + curbit;
+            }
+        }
+        int res = eval_program(c, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        ws.evals += nact;
+        unsigned long long sm = __ballot(active && res != 0);
+        if (pairlane && ((((unsigned long long)Mhi << 32) | Mlo) & sm)) hit = true;
+        if (is_uniform && sm) hs |= 1u << curbit;
+        bool all = __ballot((pairlane && !hit) || (is_uniform && hs != D)) == 0;
+        if (all) break;
+        if (stage_a_left > 0) continue;
+        if (!highmask) break;  // no high variables: the lanes covered the whole product
+        if (!stage_b) continue;
+        // advance the odometer (wave-uniform carry chain over the high variables)
+        unsigned long long hm = highmask;
+        bool carry = true;
+        while (hm && carry) {
+            int j = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
+            int nj = (int)rdlane((uint32_t)n, j);
+            if (dj == nj)
+                dj = 0;
+            else
+                carry = false;
+            if (lane == j) {
+                digit_h = dj;
+                curbit = select_kth(D, dj);
+                curval = vlb + curbit;
+            }
+        }
+        if (carry) done = true;  // wrapped around: product exhausted
+        if (++iters > (1ull << 22)) {
+            if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            return false;
+        }
+    }
+    // --- write back: supported values only
+    unsigned long long hitmask = __ballot(pairlane && hit);
+    bool ok = true;
+    for (int j = 0; j < s; j++) {
+        uint32_t Dj = rdlane(D, j);
+        uint32_t info = rdlane(varinfo, j);
+        uint32_t newD;
+        if (info) {
+            int pb = (int)rdlane((uint32_t)pairbase, j);
+            uint32_t dig = (uint32_t)(hitmask >> pb);
+            bool keep = false;
+            if (lane < 32 && ((Dj >> lane) & 1u)) {
+                int rank = __popc(Dj & ((1u << lane) - 1u));
+                keep = (dig >> rank) & 1u;
+            }
+            newD = (uint32_t)__ballot(keep);
+        } else {
+            newD = rdlane(hs, j);
+        }
+        if (newD == 0) {
+            ok = false;
+            break;
+        }
+        if (newD != Dj) {
+            int vj = (int)rdlane((uint32_t)var, j);
+            dom.set(p * c.N + vj, newD, lane);
+            if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + vj * S.cw + lane];
+        }
+    }
+    // one revision is a fixpoint for this constraint at this point: no need to revisit it for
+    // its own changes (supports are whole tuples of surviving values)
+    if (lane == (ci >> 5)) dirtyw &= ~(1u << (ci & 31));
+    return ok;
+}
+
+__device__ __forceinline__ void load_set(const Ctx &c, int set, SetDesc &S) {
+    const int *src = (const int *)&c.sets[set];
+    int *dst = (int *)&S;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = rfl(src[i]);
+}
+__device__ __forceinline__ void load_con(const Ctx &c, int idx, ConDesc &C) {
+    const int *src = (const int *)&c.cons[idx];
+    int *dst = (int *)&C;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = rfl(src[i]);
+}
+
+__device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
+    if (v) atomicAdd(&c.stats[(gw % kStatSlots) * kStatWords + which], v);
+}
+
+template <int DR>
+__device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
+                                           const Dom<DR> &dom, int lane) {
+    if (lane < 4) dst[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? h2 : h3));
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.NK) dst[4 + idx] = dom.r[q];
+    }
+}
+
+// ------------------------------------------------------------------ k_expand
+template <int DR>
+__global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wib;
+    const int r = gw % R, i = gw / R;
+    if (i >= a.take[r]) return;
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64;
+    int *lds_vals = smem + wib * per_wave;
+    int *lds_stk = lds_vals + kMaxLowVars * 64;
+    const CtlLayout L(c.world);
+    uint32_t *misc = c.ctl + L.misc0;
+
+    const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(a.count[r] - 1 - i)) * c.NS;
+    Dom<DR> dom;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        dom.r[q] = idx < c.NK ? node[4 + idx] : 0u;
+    }
+    const uint32_t h0 = rflu(node[0]), h1 = rflu(node[1]);
+    const int set = rfl((int)node[2]);
+    const uint32_t expire = rflu(node[3]);
+    SetDesc S;
+    load_set(c, set, S);
+
+    // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). The
+    // schedule is a dirty bitmask over the set's constraints (lane w holds word w); the fixpoint
+    // of monotone propagators does not depend on the order.
+    WaveStats ws;
+    uint32_t dirtyw = 0;
+    if (lane < S.cw) {
+        int left = S.ncons - lane * 32;
+        dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+    }
+    bool consistent = true;
+    unsigned guard = 0;
+    while (consistent) {
+        unsigned long long dm = __ballot(dirtyw != 0);
+        if (!dm) break;
+        int wl = __ffsll((long long)dm) - 1;
+        uint32_t word = rdlane(dirtyw, wl);
+        int b = __ffs((int)word) - 1;
+        int ci = wl * 32 + b;
+        if (lane == wl) dirtyw &= ~(1u << b);
+        ConDesc C;
+        load_con(c, S.con_begin + ci, C);
+        if (C.type == CT_NEXT) {
+            // X == next Y  <=>  X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
+            int sh = rfl(c.var_lb[C.x]) - rfl(c.var_lb[C.y]);
+            for (int p = 0; p + 1 < c.K && consistent; p++) {
+                int ix = p * c.N + C.x, iy = (p + 1) * c.N + C.y;
+                uint32_t DX = dom.get(ix), DY = dom.get(iy);
+                uint32_t Yal = sh >= 0 ? (sh < 32 ? DY >> sh : 0u) : (-sh < 32 ? DY << -sh : 0u);
+                uint32_t m = DX & Yal;
+                if (m == 0) {
+                    consistent = false;
+                    break;
+                }
+                uint32_t newY = sh >= 0 ? (m << sh) : (m >> -sh);
+                if (m != DX) {
+                    dom.set(ix, m, lane);
+                    if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + C.x * S.cw + lane];
+                }
+                if (newY != DY) {
+                    dom.set(iy, newY, lane);
+                    if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + C.y * S.cw + lane];
+                }
+            }
+            ws.revs++;
+        } else if (C.type == CT_POINT) {
+            for (int p = 0; p < C.npoints && consistent; p++)
+                consistent = revise_point<DR>(c, S, C, ci, p, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
+        } else if (C.type == CT_UNTIL) {
+            if (!((expire >> C.until_ordinal) & 1u)) {
+                uint32_t DX = dom.get(C.x), DY = dom.get(C.y);
+                if (__popc(DX) == 1 && __popc(DY) == 1) {
+                    int vx = rfl(c.var_lb[C.x]) + __ffs((int)DX) - 1, vy = rfl(c.var_lb[C.y]) + __ffs((int)DY) - 1;
+                    if (vx != 1 && vy != 1) consistent = false;
+                }
+            }
+            ws.revs++;
+        }
+        if (++guard > (1u << 20)) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            consistent = false;
+        }
+    }
+    if (lane == 0) {
+        add_stats(c, gw, ST_NODES, 1);
+        add_stats(c, gw, ST_REVS, ws.revs);
+        add_stats(c, gw, ST_EVALS, ws.evals);
+    }
+    if (!consistent) {
+        if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
+        return;
+    }
+
+    // ---- classify (solverGetFirstUnboundVar, src/solver.cpp:41-53): first variable, in queue
+    // order, whose time-0 domain is not a singleton
+    int bvar = -1;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        unsigned long long m = __ballot(idx < c.N && __popc(dom.r[q]) > 1);
+        if (bvar < 0 && m) bvar = q * 64 + __ffsll((long long)m) - 1;
+    }
+    uint32_t *out_region = a.out_base + (size_t)r * a.out_cap * c.NS;
+    if (bvar >= 0) {
+        // bisect [lb,ub] of the branching variable (variableSplitLower/Upper, variable.cpp:52-67)
+        uint32_t D = dom.get(bvar);
+        int lo = __ffs((int)D) - 1, hi = 31 - __clz((int)D);
+        int mid = lo + (hi - lo) / 2;
+        uint32_t lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + r * CST], 2u);
+        pos = rflu(pos);
+        if (pos + 2 > a.out_cap) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+            return;
+        }
+        Dom<DR> child = dom;
+        child.set(bvar, D & lowmask, lane);
+        store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set, expire, child, lane);
+        child.set(bvar, D & ~lowmask, lane);
+        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, h0, h1, (uint32_t)set, expire, child, lane);
+        return;
+    }
+
+    // ---- leaf: every variable has a single time-0 value (solveralgorithm.cpp:739-910)
+    // (1) next constraint set: per-leaf translation (:755-805) via the transition table
+    int next_set = set;
+    if (!S.self_loop) {
+        int fv = 0;
+        if (lane < S.nfirst) {
+            int v = c.firstvars[S.first_off + lane];
+            fv = v;
+        }
+        uint32_t fd = dom.gather(fv);  // time-0 word of that variable
+        int fval = (lane < S.nfirst) ? c.var_lb[fv] + __ffs((int)fd) - 1 : 0;
+        next_set = -1;
+        for (int t = 0; t < S.trans_count && next_set < 0; t++) {
+            int voff = rfl(c.trans[S.trans_begin + t].vals_off);
+            bool ne = lane < S.nfirst && c.transvals[voff + lane] != fval;
+            if (!__ballot(ne)) next_set = rfl(c.trans[S.trans_begin + t].next_set);
+        }
+        if (next_set < 0) {
+            // unknown transition: park the node again and tell the host which translation is needed
+            uint32_t mi = 0;
+            if (lane == 0) mi = atomicAdd(&misc[MISC_NMISS * CST], 1u);
+            mi = rflu(mi);
+            if ((int)mi < c.miss_cap) {
+                int *rec = c.miss + (size_t)mi * kMissStride;
+                if (lane == 0) {
+                    rec[0] = set;
+                    rec[1] = S.nfirst;
+                }
+                if (lane < S.nfirst) rec[2 + lane] = fval;
+            }
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + r * CST], 1u);
+            pos = rflu(pos);
+            if (pos + 1 > a.out_cap) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+                return;
+            }
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set, expire, dom, lane);
+            if (lane == 0) add_stats(c, gw, ST_REQUEUE, 1);
+            return;
+        }
+    }
+    const uint32_t next_tag = (uint32_t)rfl(c.sets[next_set].tag);
+    // (2) signature (:812-837): signature variables in queue order, then one sticky flag per until
+    uint32_t new_expire = expire;
+    uint32_t kw = 0;  // lane j holds key word j: [tag, sig...]
+    {
+        int sv = 0;
+        if (lane >= 1 && lane <= c.n_sig) sv = c.sig_vars[lane - 1];
+        uint32_t sd = dom.gather(sv);
+        if (lane >= 1 && lane <= c.n_sig) kw = (uint32_t)(c.var_lb[sv] + __ffs((int)sd) - 1);
+        for (int u = 0; u < c.n_until_cons; u++) {
+            int y = rfl(c.until_y[u]);
+            uint32_t DY = dom.get(y);
+            bool ex = (expire >> u) & 1u;
+            if (!ex && rfl(c.var_lb[y]) + __ffs((int)DY) - 1 == 1) {
+                ex = true;
+                new_expire |= 1u << u;
+            }
+            if (lane == 1 + c.n_sig + u) kw = ex ? 1u : 0u;
+        }
+        if (lane == 0) kw = next_tag;
+    }
+    // (3) owner shard = hash(key) % world
+    unsigned long long h = kHashSeed;
+    for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
+    h = mix_final(h);
+    const int owner = (int)((h >> 40) % (unsigned)c.world);
+    // (4) candidate record: header, signature, edge label, time-advanced block
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(&c.ctl[L.cand0 + (owner * R + r) * CST], 1u);
+    pos = rflu(pos);
+    if (pos + 1 > a.cand_cap) {
+        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
+        return;
+    }
+    uint32_t *rec = a.cand_base + ((size_t)(owner * R + r) * a.cand_cap + pos) * c.CS;
+    if (lane < 4) rec[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? next_tag : new_expire));
+    if (lane >= 1 && lane <= c.sig_len) rec[4 + lane - 1] = kw;
+    uint32_t *vals = rec + 4 + c.sig_len;
+    uint32_t *blk = vals + c.N;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.N) vals[idx] = (uint32_t)(c.var_lb[idx] + __ffs((int)dom.r[q]) - 1);  // Edge::values
+    }
+    // variableAdvanceOneTimeStep (variable.cpp:94-108): point p <- point p+1, last point <- [lb,ub]
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
+        if (idx < c.NK) {
+            int p = idx / c.N, v = idx - p * c.N;
+            blk[idx] = (p + 1 < c.K) ? shifted : c.var_init[v];
+        }
+    }
+    if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+}
+
+// ------------------------------------------------------------------ k_commit
+__global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const long long gw = (long long)blockIdx.x * 4 + wib;
+    const int r = (int)(gw % R);
+    const CtlLayout L(c.world);
+    uint32_t *misc = c.ctl + L.misc0;
+    const uint32_t *rec;
+    if (a.regions) {
+        long long i = gw / R;
+        uint32_t cnt = c.ctl[a.cand_cursor_base + r * CST];
+        if (i >= (long long)cnt) return;
+        rec = a.cand_base + ((size_t)r * a.cand_cap + (size_t)i) * c.CS;
+    } else {
+        if (gw >= a.total) return;
+        rec = a.cand_base + (size_t)gw * c.CS;
+    }
+    const uint32_t s0 = rflu(rec[0]), s1 = rflu(rec[1]), tag = rflu(rec[2]), expire = rflu(rec[3]);
+    uint32_t kw = 0;
+    if (lane == 0) kw = tag;
+    if (lane >= 1 && lane <= c.sig_len) kw = rec[4 + lane - 1];
+    unsigned long long h = kHashSeed;
+    for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
+    h = mix_final(h);
+    const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
+    uint32_t pos = (uint32_t)h & c.slot_mask;
+
+    // lookup-or-insert (vertexTableGetVertex / vertexNew + vertexTableAddVertex)
+    uint32_t idx = 0;
+    bool is_new = false;
+    for (unsigned probes = 0;; probes++) {
+        unsigned long long sv = 0;
+        bool claimed = false;
+        if (lane == 0) {
+            sv = __hip_atomic_load(&c.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sv == 0) {
+                unsigned long long want = ((unsigned long long)htag << 32) | kPending;
+                unsigned long long old = atomicCAS(&c.slots[pos], 0ull, want);
+                claimed = old == 0;
+                sv = old;
+            }
+        }
+        uint32_t lo = rflu((uint32_t)sv), hi = rflu((uint32_t)(sv >> 32));
+        if (__ballot(claimed)) {
+            // claimed: allocate the state, publish its key, then publish the index
+            uint32_t ni = 0;
+            if (lane == 0) ni = atomicAdd(&misc[MISC_NSTATES * CST], 1u);
+            ni = rflu(ni);
+            if (ni >= c.state_cap) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
+                return;
+            }
+            if (lane < c.KL) __hip_atomic_store(&c.state_keys[(size_t)ni * c.KL + lane], kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(&c.slots[pos], ((unsigned long long)htag << 32) | ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idx = ni;
+            is_new = true;
+            break;
+        }
+        if (hi == htag) {
+            unsigned spins = 0;
+            while (lo == kPending) {  // another wavefront is publishing this slot
+                __builtin_amdgcn_s_sleep(2);
+                unsigned long long t = 0;
+                if (lane == 0) t = __hip_atomic_load(&c.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = rflu((uint32_t)t);
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_TABLE_SPIN);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint32_t other = 0;
+            if (lane < c.KL) other = __hip_atomic_load(&c.state_keys[(size_t)lo * c.KL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__ballot(lane < c.KL && other != kw)) {
+                idx = lo;
+                break;
+            }
+        }
+        pos = (pos + 1) & c.slot_mask;
+        if (probes > c.slot_mask) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
+            return;
+        }
+    }
+    // edge record: src (global id), dst (local index), label = time-0 value of every variable
+    uint32_t e = 0;
+    if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + r * CST], 1u);
+    e = rflu(e);
+    if (e >= c.edge_cap) {
+        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_EDGE_OVERFLOW);
+        return;
+    }
+    uint32_t *er = c.edges + ((size_t)r * c.edge_cap + e) * c.ES;
+    if (lane < 4) er[lane] = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? idx : 0u));
+    const uint32_t *vals = rec + 4 + c.sig_len;
+    for (int v = lane; v < c.N; v += 64) er[4 + v] = vals[v];
+    if (!is_new) return;
+    // new state: open its first search node (the successor block travelled with the candidate)
+    int set = -1;
+    for (int s = 0; s < c.nsets && set < 0; s++)
+        if ((uint32_t)rfl(c.sets[s].tag) == tag) set = s;
+    if (set < 0) {
+        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
+        return;
+    }
+    uint32_t np = 0;
+    if (lane == 0) np = atomicAdd(&c.ctl[L.out0 + r * CST], 1u);
+    np = rflu(np);
+    if (np + 1 > a.out_cap) {
+        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+        return;
+    }
+    uint32_t *dst = a.out_base + ((size_t)r * a.out_cap + np) * c.NS;
+    const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | idx;
+    if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)set : expire));
+    const uint32_t *blk = vals + c.N;
+    for (int k = lane; k < c.NK; k += 64) dst[4 + k] = blk[k];
+    if (lane == 0) add_stats(c, (int)(gw & 0x7fffffff), ST_NEWSTATES, 1);
+}
+
+// gather the R regions of one owner's outbox into a contiguous array (for the all-to-all)
+__global__ void k_pack(const uint32_t *cand_base, uint32_t cand_cap, int CS, const uint32_t *ctl, int cursor_base,
+                       uint32_t *dst) {
+    __shared__ uint32_t pref[R + 1];
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int r = 0; r < R; r++) {
+            pref[r] = acc;
+            acc += ctl[cursor_base + r * CST];
+        }
+        pref[R] = acc;
+    }
+    __syncthreads();
+    const size_t total_words = (size_t)pref[R] * CS;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += (size_t)gridDim.x * blockDim.x) {
+        uint32_t recno = (uint32_t)(w / CS), off = (uint32_t)(w % CS);
+        int r = 0;
+        while (recno >= pref[r + 1]) r++;
+        dst[w] = cand_base[((size_t)r * cand_cap + (recno - pref[r])) * CS + off];
+    }
+}
+
+// re-insert every state into a larger table
+__global__ void k_rehash(Ctx c, uint32_t n_states) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    unsigned long long h = kHashSeed;
+    for (int j = 0; j < c.KL; j++) h = mix64(h, c.state_keys[(size_t)i * c.KL + j]);
+    h = mix_final(h);
+    const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
+    uint32_t pos = (uint32_t)h & c.slot_mask;
+    const unsigned long long want = ((unsigned long long)htag << 32) | i;
+    while (atomicCAS(&c.slots[pos], 0ull, want) != 0ull) pos = (pos + 1) & c.slot_mask;
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+};
+
+struct Segment {
+    size_t base;   // word offset into the arena
+    uint32_t cap;  // node slots per region
+    int count[R];
+    long long total() const {
+        long long t = 0;
+        for (int r = 0; r < R; r++) t += count[r];
+        return t;
+    }
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct stcsp_engine {
+    SetManager mgr;
+    FlatProgram prog;
+    stcsp_options opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Ctx ctx{};
+    int DR = 1;
+    CtlLayout L{1};
+    size_t lds_bytes = 0;
+    int chunk_r = 0;  // max nodes taken per region per launch
+
+    DevBuf<int> d_var_lb, d_arr_off, d_arr_data, d_sig_vars, d_until_y, d_scope, d_code, d_firstvars, d_transvals, d_miss;
+    DevBuf<uint32_t> d_var_init, d_varcons, d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack;
+    DevBuf<SetDesc> d_sets;
+    DevBuf<ConDesc> d_cons;
+    DevBuf<TransDesc> d_trans;
+    DevBuf<unsigned long long> d_slots, d_stats;
+    uint32_t *h_ctl = nullptr;  // pinned
+    int *h_miss = nullptr;      // pinned
+    uint32_t cand_cap = 0;
+    size_t arena_top = 0;
+    std::vector<Segment> stack;
+    std::vector<uint32_t> edge_count = std::vector<uint32_t>(R, 0);
+    uint32_t n_states = 0;
+    bool begun = false, finished = false;
+    bool truncated = false;
+    std::chrono::steady_clock::time_point t_begin;
+    double seconds_search = 0, seconds_export = 0;
+    long long levels = 0;
+    std::string err;
+
+    // export storage
+    std::vector<int32_t> r_cid, r_sig, r_eval;
+    std::vector<uint8_t> r_fail, r_issig;
+    std::vector<int64_t> r_esrc, r_edst;
+
+    ~stcsp_engine() {
+        if (h_ctl) (void)hipHostFree(h_ctl);
+        if (h_miss) (void)hipHostFree(h_miss);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+#define HIPCHK(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail(STCSP_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+    int upload_program() {
+        int rc = mgr.compile(prog);
+        if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
+        HIPCHK(d_sets.upload(prog.sets));
+        HIPCHK(d_cons.upload(prog.cons));
+        HIPCHK(d_scope.upload(prog.scope));
+        HIPCHK(d_code.upload(prog.code));
+        HIPCHK(d_firstvars.upload(prog.firstvars));
+        HIPCHK(d_trans.upload(prog.trans));
+        HIPCHK(d_transvals.upload(prog.transvals));
+        HIPCHK(d_varcons.upload(prog.varcons));
+        ctx.sets = d_sets.p;
+        ctx.cons = d_cons.p;
+        ctx.scope = d_scope.p;
+        ctx.code = d_code.p;
+        ctx.firstvars = d_firstvars.p;
+        ctx.trans = d_trans.p;
+        ctx.transvals = d_transvals.p;
+        ctx.varcons = d_varcons.p;
+        ctx.nsets = (int)prog.sets.size();
+        ctx.stack_slots = prog.max_stack + 2;
+        lds_bytes = (size_t)4 * (kMaxLowVars + ctx.stack_slots) * 64 * sizeof(int);
+        if (lds_bytes > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
+        return STCSP_OK;
+    }
+
+    int create(const stcsp_problem *p, const stcsp_options *o) {
+        if (o) opt = *o;
+        if (opt.world <= 0) opt.world = 1;
+        if (opt.rank < 0 || opt.rank >= opt.world) return fail(STCSP_E_INVALID, "rank %d outside world %d", opt.rank, opt.world);
+        int rc = mgr.init(p, opt.world > 1);
+        if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
+        const int N = mgr.N, K = mgr.K;
+        for (int v = 0; v < N; v++) {
+            long long width = (long long)mgr.ub[v] - (long long)mgr.lb[v] + 1;
+            if (width > 32)
+                return fail(STCSP_E_UNSUPPORTED, "variable %d has %lld values; this engine packs at most 32 per bitset word", v, width);
+        }
+        if ((long long)N * K > 64 * kMaxDomRegs)
+            return fail(STCSP_E_UNSUPPORTED, "N*K = %d exceeds the %d-word register-resident block", N * K, 64 * kMaxDomRegs);
+        if (mgr.n_until_cons > 32) return fail(STCSP_E_UNSUPPORTED, "more than 32 until constraints");
+        if (1 + mgr.n_sig + mgr.n_until_cons > 64) return fail(STCSP_E_UNSUPPORTED, "signature longer than 63 words");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(STCSP_E_DEVICE, "no HIP device available");
+        device = opt.device;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&stream));
+        L = CtlLayout(opt.world);
+        ctx.N = N;
+        ctx.K = K;
+        ctx.NK = N * K;
+        ctx.NS = node_stride(N, K);
+        ctx.sig_len = mgr.n_sig + mgr.n_until_cons;
+        ctx.n_sig = mgr.n_sig;
+        ctx.n_until_cons = mgr.n_until_cons;
+        ctx.KL = 1 + ctx.sig_len;
+        ctx.CS = cand_stride(N, K, ctx.sig_len);
+        ctx.ES = edge_stride(N);
+        ctx.world = opt.world;
+        ctx.rank = opt.rank;
+        DR = (N * K + 63) / 64;
+        if (DR == 3) DR = 4;
+        std::vector<uint32_t> init(N);
+        for (int v = 0; v < N; v++) {
+            int w = mgr.ub[v] - mgr.lb[v] + 1;
+            init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
+        }
+        HIPCHK(d_var_lb.upload(mgr.lb));
+        HIPCHK(d_var_init.upload(init));
+        HIPCHK(d_arr_off.upload(mgr.array_off));
+        HIPCHK(d_arr_data.upload(mgr.array_data));
+        HIPCHK(d_sig_vars.upload(mgr.sig_vars));
+        HIPCHK(d_until_y.upload(mgr.until_y));
+        ctx.var_lb = d_var_lb.p;
+        ctx.var_init = d_var_init.p;
+        ctx.arr_off = d_arr_off.p;
+        ctx.arr_data = d_arr_data.p;
+        ctx.sig_vars = d_sig_vars.p;
+        ctx.until_y = d_until_y.p;
+        rc = upload_program();
+        if (rc != STCSP_OK) return rc;
+        // pools
+        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : 65536;
+        chunk_r = std::max(1, (batch + R - 1) / R);
+        HIPCHK(d_ctl.alloc(L.words));
+        HIPCHK(hipHostMalloc((void **)&h_ctl, L.words * sizeof(uint32_t)));
+        ctx.ctl = d_ctl.p;
+        ctx.miss_cap = 4096;
+        HIPCHK(d_miss.alloc((size_t)ctx.miss_cap * kMissStride));
+        HIPCHK(hipHostMalloc((void **)&h_miss, (size_t)ctx.miss_cap * kMissStride * sizeof(int)));
+        ctx.miss = d_miss.p;
+        HIPCHK(d_stats.alloc(kStatSlots * kStatWords));
+        ctx.stats = d_stats.p;
+        rc = alloc_table(1u << 20);
+        if (rc != STCSP_OK) return rc;
+        rc = alloc_states(1u << 19);
+        if (rc != STCSP_OK) return rc;
+        rc = alloc_edges(1u << 15);
+        if (rc != STCSP_OK) return rc;
+        // outbox: [owner][region] x cand_cap records. Unsharded: emptied after every launch.
+        cand_cap = (uint32_t)(opt.world > 1 ? std::max(4 * chunk_r, 4096) : chunk_r);
+        HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
+        if (opt.world > 1) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
+        // arena of node segments (grown on demand)
+        HIPCHK(d_arena.alloc((size_t)8 * R * chunk_r * ctx.NS));
+        return STCSP_OK;
+    }
+
+    int alloc_table(uint32_t slots) {
+        HIPCHK(d_slots.alloc(slots));
+        HIPCHK(hipMemsetAsync(d_slots.p, 0, (size_t)slots * sizeof(unsigned long long), stream));
+        ctx.slots = d_slots.p;
+        ctx.slot_mask = slots - 1;
+        return STCSP_OK;
+    }
+    int alloc_states(uint32_t cap) {
+        DevBuf<uint32_t> nb;
+        HIPCHK(nb.alloc((size_t)cap * ctx.KL));
+        if (d_state_keys.p && n_states)
+            HIPCHK(hipMemcpyAsync(nb.p, d_state_keys.p, (size_t)n_states * ctx.KL * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::swap(d_state_keys.p, nb.p);
+        std::swap(d_state_keys.n, nb.n);
+        ctx.state_keys = d_state_keys.p;
+        ctx.state_cap = cap;
+        return STCSP_OK;
+    }
+    int alloc_edges(uint32_t cap) {
+        DevBuf<uint32_t> nb;
+        HIPCHK(nb.alloc((size_t)R * cap * ctx.ES));
+        if (d_edges.p)
+            for (int r = 0; r < R; r++)
+                if (edge_count[r])
+                    HIPCHK(hipMemcpyAsync(nb.p + (size_t)r * cap * ctx.ES, d_edges.p + (size_t)r * ctx.edge_cap * ctx.ES,
+                                          (size_t)edge_count[r] * ctx.ES * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::swap(d_edges.p, nb.p);
+        std::swap(d_edges.n, nb.n);
+        ctx.edges = d_edges.p;
+        ctx.edge_cap = cap;
+        return STCSP_OK;
+    }
+    // make room for `incoming` more leaves/states before a launch, so kernels never overflow
+    int ensure_capacity(long long incoming, long long per_region) {
+        uint32_t max_edges = 0;
+        for (int r = 0; r < R; r++) max_edges = std::max(max_edges, edge_count[r]);
+        if ((long long)max_edges + per_region > (long long)ctx.edge_cap) {
+            uint64_t cap = ctx.edge_cap;
+            while ((long long)max_edges + per_region > (long long)cap) cap *= 2;
+            if (cap > 0x7fffffffull) return fail(STCSP_E_NOMEM, "edge log too large");
+            int rc = alloc_edges((uint32_t)cap);
+            if (rc != STCSP_OK) return rc;
+        }
+        if ((long long)n_states + incoming > (long long)ctx.state_cap) {
+            uint64_t cap = ctx.state_cap;
+            while ((long long)n_states + incoming > (long long)cap) cap *= 2;
+            if (cap > 0x7fffffffull) return fail(STCSP_E_NOMEM, "state pool too large");
+            int rc = alloc_states((uint32_t)cap);
+            if (rc != STCSP_OK) return rc;
+        }
+        if (((long long)n_states + incoming) * 2 > (long long)ctx.slot_mask + 1) {
+            uint64_t slots = (uint64_t)ctx.slot_mask + 1;
+            while (((long long)n_states + incoming) * 2 > (long long)slots) slots *= 2;
+            if (slots > (1ull << 31)) return fail(STCSP_E_NOMEM, "state table too large");
+            int rc = alloc_table((uint32_t)slots);
+            if (rc != STCSP_OK) return rc;
+            if (n_states) hipLaunchKernelGGL(k_rehash, dim3((n_states + 255) / 256), dim3(256), 0, stream, ctx, n_states);
+            HIPCHK(hipGetLastError());
+        }
+        return STCSP_OK;
+    }
+    int ensure_arena(size_t words_needed) {
+        if (arena_top + words_needed <= d_arena.n) return STCSP_OK;
+        size_t want = std::max(d_arena.n * 2, arena_top + words_needed);
+        DevBuf<uint32_t> nb;
+        if (nb.alloc(want) != hipSuccess) return fail(STCSP_E_NOMEM, "cannot grow the frontier arena to %zu MiB", want * 4 >> 20);
+        HIPCHK(hipMemcpyAsync(nb.p, d_arena.p, arena_top * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::swap(d_arena.p, nb.p);
+        std::swap(d_arena.n, nb.n);
+        return STCSP_OK;
+    }
+
+    int begin() {
+        HIPCHK(hipSetDevice(device));
+        stack.clear();
+        arena_top = 0;
+        std::fill(edge_count.begin(), edge_count.end(), 0u);
+        n_states = 0;
+        truncated = false;
+        levels = 0;
+        finished = false;
+        HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
+        if (opt.rank == 0) {
+            // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
+            // With an empty signature a leaf of set 0 must find it again, so the key is the plain
+            // (tag 0); otherwise a reserved tag keeps it apart from a state with an all-zero signature.
+            std::vector<uint32_t> key(ctx.KL, 0u);
+            key[0] = ctx.sig_len == 0 ? 0u : kRootTag;
+            unsigned long long h = kHashSeed;
+            for (int j = 0; j < ctx.KL; j++) h = mix64(h, key[j]);
+            h = mix_final(h);
+            uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
+            unsigned long long slot = ((unsigned long long)htag << 32) | 0u;
+            HIPCHK(hipMemcpyAsync(d_state_keys.p, key.data(), ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_slots.p + ((uint32_t)h & ctx.slot_mask), &slot, sizeof slot, hipMemcpyHostToDevice, stream));
+            uint32_t one = 1;
+            HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NSTATES * CST, &one, sizeof one, hipMemcpyHostToDevice, stream));
+            n_states = 1;
+            // root search node: initial domains at every point (variable.cpp:24-29), set 0
+            std::vector<uint32_t> node(ctx.NS, 0u);
+            for (int p = 0; p < ctx.K; p++)
+                for (int v = 0; v < ctx.N; v++) {
+                    int w = mgr.ub[v] - mgr.lb[v] + 1;
+                    node[4 + p * ctx.N + v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
+                }
+            Segment s{};
+            s.base = 0;
+            s.cap = 1;
+            s.count[0] = 1;
+            int rc = ensure_arena((size_t)R * ctx.NS);
+            if (rc != STCSP_OK) return rc;
+            HIPCHK(hipMemcpyAsync(d_arena.p, node.data(), ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            arena_top = (size_t)R * 1 * ctx.NS;
+            stack.push_back(s);
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        begun = true;
+        t_begin = std::chrono::steady_clock::now();
+        return STCSP_OK;
+    }
+
+    double elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
+
+    int read_ctl() {
+        HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t e = h_ctl[L.misc0 + MISC_ERROR * CST];
+        if (e) {
+            static const char *names[] = {"", "watchdog", "table spin", "edge overflow", "state overflow", "unknown set",
+                                          "empty domain", "frontier overflow", "candidate overflow"};
+            return fail(e == ERR_WATCHDOG ? STCSP_E_INTERNAL : STCSP_E_NOMEM, "device reported error %u (%s)", e, e < 9 ? names[e] : "?");
+        }
+        return STCSP_OK;
+    }
+
+    template <int DRT>
+    void launch_expand(const ExpandArgs &a, int maxtake) {
+        int waves = R * maxtake;
+        hipLaunchKernelGGL((k_expand<DRT>), dim3((waves + 3) / 4), dim3(256), lds_bytes, stream, ctx, a);
+    }
+
+    int service_misses() {
+        uint32_t nm = h_ctl[L.misc0 + MISC_NMISS * CST];
+        if (!nm) return STCSP_OK;
+        uint32_t n = std::min<uint32_t>(nm, (uint32_t)ctx.miss_cap);
+        HIPCHK(hipMemcpyAsync(h_miss, d_miss.p, (size_t)n * kMissStride * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < n; i++) {
+            const int *rec = h_miss + (size_t)i * kMissStride;
+            std::vector<int> vals(rec + 2, rec + 2 + rec[1]);
+            int ns = mgr.transition(rec[0], vals);
+            if (ns < 0) return fail(ns, "%s", mgr.error.c_str());
+        }
+        uint32_t zero = 0;
+        HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NMISS * CST, &zero, sizeof zero, hipMemcpyHostToDevice, stream));
+        return upload_program();
+    }
+
+    // one launch round on the top segment: expand a chunk; unsharded engines commit right away
+    int step(bool commit_local) {
+        Segment &S = stack.back();
+        ExpandArgs a{};
+        int maxtake = 0;
+        long long taken = 0;
+        for (int r = 0; r < R; r++) {
+            a.count[r] = S.count[r];
+            a.take[r] = std::min(S.count[r], chunk_r);
+            maxtake = std::max(maxtake, a.take[r]);
+            taken += a.take[r];
+        }
+        int rc = ensure_capacity(taken, maxtake);
+        if (rc != STCSP_OK) return rc;
+        Segment T{};
+        T.base = arena_top;
+        T.cap = (uint32_t)(2 * maxtake);
+        rc = ensure_arena((size_t)R * T.cap * ctx.NS);
+        if (rc != STCSP_OK) return rc;
+        // zero the out cursors (and, unsharded, the outbox cursors): contiguous at the start of ctl
+        size_t zero_words = commit_local ? (size_t)L.edge0 : (size_t)L.cand0;
+        HIPCHK(hipMemsetAsync(d_ctl.p, 0, zero_words * sizeof(uint32_t), stream));
+        a.in_base = d_arena.p + S.base;
+        a.in_cap = S.cap;
+        a.out_base = d_arena.p + T.base;
+        a.out_cap = T.cap;
+        a.cand_base = d_cand.p;
+        a.cand_cap = cand_cap;
+        switch (DR) {
+            case 1: launch_expand<1>(a, maxtake); break;
+            case 2: launch_expand<2>(a, maxtake); break;
+            default: launch_expand<4>(a, maxtake); break;
+        }
+        HIPCHK(hipGetLastError());
+        if (commit_local) {
+            CommitArgs ca{};
+            ca.cand_base = d_cand.p;
+            ca.cand_cap = cand_cap;
+            ca.regions = 1;
+            ca.cand_cursor_base = L.cand0;
+            ca.out_base = a.out_base;
+            ca.out_cap = a.out_cap;
+            int waves = R * maxtake;
+            hipLaunchKernelGGL(k_commit, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, ca);
+            HIPCHK(hipGetLastError());
+        }
+        rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
+        levels++;
+        for (int r = 0; r < R; r++) {
+            S.count[r] -= a.take[r];
+            T.count[r] = (int)h_ctl[L.out0 + r * CST];
+            edge_count[r] = h_ctl[L.edge0 + r * CST];
+        }
+        n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
+        rc = service_misses();
+        if (rc != STCSP_OK) return rc;
+        if (T.total() > 0) {
+            arena_top = T.base + (size_t)R * T.cap * ctx.NS;
+            stack.push_back(T);  // (invalidates S)
+        }
+        // drop exhausted segments from the top
+        while (!stack.empty() && stack.back().total() == 0) {
+            arena_top = stack.back().base;
+            stack.pop_back();
+        }
+        return STCSP_OK;
+    }
+
+    bool over_budget() {
+        if (opt.time_limit_s > 0 && elapsed() > opt.time_limit_s) return true;
+        if (opt.max_search_nodes > 0) {
+            // cheap upper bound without a device read: every launch expands at most R*chunk_r nodes
+            if (levels * (long long)R * chunk_r >= opt.max_search_nodes) {
+                std::vector<unsigned long long> st(kStatSlots * kStatWords);
+                if (hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                    long long nodes = 0;
+                    for (int s = 0; s < kStatSlots; s++) nodes += (long long)st[s * kStatWords + ST_NODES];
+                    if (nodes >= opt.max_search_nodes) return true;
+                }
+            }
+        }
+        return false;
+    }
+
+    int solve_unsharded() {
+        int rc = begin();
+        if (rc != STCSP_OK) return rc;
+        while (!stack.empty()) {
+            if (over_budget()) {
+                truncated = true;
+                break;
+            }
+            rc = step(true);
+            if (rc != STCSP_OK) return rc;
+        }
+        return finish();
+    }
+
+    int finish() {
+        HIPCHK(hipStreamSynchronize(stream));
+        seconds_search = elapsed();
+        finished = true;
+        return STCSP_OK;
+    }
+
+    // ---- sharded stepping
+    long long open_nodes() const {
+        long long t = 0;
+        for (auto &s : stack) t += s.total();
+        return t;
+    }
+    int expand_local(int64_t *left) {
+        if (!begun) return fail(STCSP_E_STATE, "expand_local before begin");
+        int rc;
+        while (!stack.empty()) {
+            // stop while every outbox bucket still has room for one more launch
+            uint32_t max_bucket = 0;
+            for (int o = 0; o < opt.world; o++)
+                for (int r = 0; r < R; r++) max_bucket = std::max(max_bucket, h_ctl[L.cand0 + (o * R + r) * CST]);
+            if ((long long)max_bucket + chunk_r > (long long)cand_cap) break;
+            if (over_budget()) {
+                truncated = true;
+                break;
+            }
+            rc = step(false);
+            if (rc != STCSP_OK) return rc;
+        }
+        if (left) *left = truncated ? 0 : open_nodes();
+        return STCSP_OK;
+    }
+    int outbox(int peer, void **ptr, int64_t *count) {
+        if (peer < 0 || peer >= opt.world) return fail(STCSP_E_INVALID, "peer out of range");
+        uint32_t total = 0;
+        for (int r = 0; r < R; r++) total += h_ctl[L.cand0 + (peer * R + r) * CST];
+        // pack this peer's regions; each peer gets its own slice of the pack buffer
+        if (d_pack.n < (size_t)opt.world * R * cand_cap * ctx.CS) HIPCHK(d_pack.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
+        uint32_t *dst = d_pack.p + (size_t)peer * R * cand_cap * ctx.CS;
+        if (total) {
+            hipLaunchKernelGGL(k_pack, dim3(std::min<uint32_t>(1024, (total * ctx.CS + 255) / 256)), dim3(256), 0, stream,
+                               d_cand.p + (size_t)peer * R * cand_cap * ctx.CS, cand_cap, ctx.CS, d_ctl.p, L.cand0 + peer * R * CST, dst);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        *ptr = dst;
+        *count = total;
+        return STCSP_OK;
+    }
+    int commit(const void *records, int64_t count) {
+        if (!begun) return fail(STCSP_E_STATE, "commit before begin");
+        // the outbox has been handed over: empty it
+        HIPCHK(hipMemsetAsync(d_ctl.p + L.cand0, 0, (size_t)(L.edge0 - L.cand0) * sizeof(uint32_t), stream));
+        for (int i = L.cand0; i < L.edge0; i++) h_ctl[i] = 0;
+        if (count <= 0) {
+            HIPCHK(hipStreamSynchronize(stream));
+            return STCSP_OK;
+        }
+        int rc = ensure_capacity(count, (count + R - 1) / R + 1);
+        if (rc != STCSP_OK) return rc;
+        Segment T{};
+        T.base = arena_top;
+        T.cap = (uint32_t)((count + R - 1) / R + 1);
+        rc = ensure_arena((size_t)R * T.cap * ctx.NS);
+        if (rc != STCSP_OK) return rc;
+        HIPCHK(hipMemsetAsync(d_ctl.p, 0, (size_t)L.cand0 * sizeof(uint32_t), stream));
+        CommitArgs ca{};
+        ca.cand_base = (const uint32_t *)records;
+        ca.regions = 0;
+        ca.total = count;
+        ca.out_base = d_arena.p + T.base;
+        ca.out_cap = T.cap;
+        hipLaunchKernelGGL(k_commit, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, ctx, ca);
+        HIPCHK(hipGetLastError());
+        rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
+        for (int r = 0; r < R; r++) {
+            T.count[r] = (int)h_ctl[L.out0 + r * CST];
+            edge_count[r] = h_ctl[L.edge0 + r * CST];
+        }
+        n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
+        if (T.total() > 0) {
+            arena_top = T.base + (size_t)R * T.cap * ctx.NS;
+            stack.push_back(T);
+        }
+        return STCSP_OK;
+    }
+
+    int export_result(stcsp_result *res) {
+        auto t0 = std::chrono::steady_clock::now();
+        HIPCHK(hipSetDevice(device));
+        const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N, ES = ctx.ES;
+        std::vector<uint32_t> keys((size_t)n_states * KL);
+        if (n_states) HIPCHK(hipMemcpy(keys.data(), d_state_keys.p, keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        r_cid.assign(n_states, 0);
+        r_sig.assign((size_t)n_states * std::max(sl, 0), 0);
+        for (uint32_t i = 0; i < n_states; i++) {
+            uint32_t tag = keys[(size_t)i * KL];
+            r_cid[i] = (tag == kRootTag) ? 0 : (int32_t)tag;
+            for (int j = 0; j < sl; j++) r_sig[(size_t)i * sl + j] = (int32_t)keys[(size_t)i * KL + 1 + j];
+        }
+        size_t E = 0;
+        for (int r = 0; r < R; r++) E += edge_count[r];
+        r_esrc.resize(E);
+        r_edst.resize(E);
+        r_eval.resize(E * N);
+        std::vector<uint32_t> buf;
+        size_t e = 0;
+        for (int r = 0; r < R; r++) {
+            if (!edge_count[r]) continue;
+            buf.resize((size_t)edge_count[r] * ES);
+            HIPCHK(hipMemcpy(buf.data(), d_edges.p + (size_t)r * ctx.edge_cap * ES, buf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < edge_count[r]; k++, e++) {
+                const uint32_t *er = buf.data() + (size_t)k * ES;
+                int64_t src = (int64_t)(((uint64_t)er[1] << 32) | er[0]);
+                int64_t dst = ((int64_t)opt.rank << STCSP_GID_SHIFT) | er[2];
+                r_esrc[e] = src;
+                r_edst[e] = dst;
+                memcpy(&r_eval[e * N], er + 4, (size_t)N * sizeof(int32_t));
+            }
+        }
+        // counters
+        std::vector<unsigned long long> st(kStatSlots * kStatWords);
+        HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long tot[kStatWords] = {0};
+        for (int s = 0; s < kStatSlots; s++)
+            for (int k = 0; k < kStatWords; k++) tot[k] += st[s * kStatWords + k];
+        stcsp_counters ctr{};
+        ctr.search_nodes = (int64_t)(tot[ST_NODES] - tot[ST_REQUEUE]);
+        ctr.gac_calls = (int64_t)tot[ST_NODES];
+        ctr.fails = (int64_t)tot[ST_FAILS];
+        ctr.leaves = (int64_t)tot[ST_LEAVES];
+        ctr.revisions = (int64_t)tot[ST_REVS];
+        ctr.evaluations = (int64_t)tot[ST_EVALS];
+        ctr.levels = levels;
+        ctr.seconds_search = seconds_search;
+        r_fail.assign(n_states, 0);
+        if (opt.world == 1) {
+            // ok-fixpoint over the raw leaf-edge log (okfix.hpp); sharded runs do it after the merge
+            std::vector<uint8_t> alive;
+            ok_fixpoint(n_states, r_esrc, r_edst, r_fail, alive);
+            if (!(opt.flags & STCSP_F_KEEP_RAW_EDGES)) {
+                size_t w = 0;
+                for (size_t k = 0; k < E; k++)
+                    if (alive[k]) {
+                        r_esrc[w] = r_esrc[k];
+                        r_edst[w] = r_edst[k];
+                        if (w != k) memmove(&r_eval[w * N], &r_eval[k * N], (size_t)N * sizeof(int32_t));
+                        w++;
+                    }
+                r_esrc.resize(w);
+                r_edst.resize(w);
+                r_eval.resize(w * N);
+                E = w;
+            }
+            int64_t ok_states = 0, live = 0;
+            for (uint32_t v = 1; v < n_states; v++) ok_states += !r_fail[v];
+            for (size_t k = 0; k < alive.size(); k++) live += alive[k];
+            ctr.dominance = live - ok_states;  // every ok non-root state is entered by exactly one creating leaf
+        }
+        r_issig.assign(mgr.is_sig.begin(), mgr.is_sig.end());
+        memset(res, 0, sizeof *res);
+        res->n_states = n_states;
+        res->sig_len = sl;
+        res->n_sig_vars = mgr.n_sig;
+        res->n_until = mgr.n_until;
+        res->n_until_cons = mgr.n_until_cons;
+        res->state_cid = r_cid.data();
+        res->state_sig = r_sig.data();
+        res->state_fail = r_fail.data();
+        res->n_edges = (int64_t)E;
+        res->edge_src = r_esrc.data();
+        res->edge_dst = r_edst.data();
+        res->edge_values = r_eval.data();
+        res->n_vars = N;
+        res->n_constraint_sets = (int32_t)mgr.sets.size();
+        res->var_is_signature = r_issig.data();
+        res->root_final = mgr.n_until_cons == 0;
+        res->truncated = truncated;
+        seconds_export = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ctr.seconds_export = seconds_export;
+        res->counters = ctr;
+        return STCSP_OK;
+    }
+};
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+int stcsp_engine_create(const stcsp_problem *problem, const stcsp_options *options, stcsp_engine **out) {
+    if (!problem || !out) {
+        g_create_error = "null argument";
+        return STCSP_E_INVALID;
+    }
+    std::unique_ptr<stcsp_engine> e(new stcsp_engine());
+    int rc = e->create(problem, options);
+    if (rc != STCSP_OK) {
+        g_create_error = e->err;
+        return rc;
+    }
+    *out = e.release();
+    return STCSP_OK;
+}
+
+int stcsp_engine_solve(stcsp_engine *e, stcsp_result *result) {
+    if (!e || !result) return STCSP_E_INVALID;
+    if (e->opt.world != 1) return e->fail(STCSP_E_STATE, "solve() is the unsharded entry point; use the stepping calls when world > 1");
+    int rc = e->solve_unsharded();
+    if (rc != STCSP_OK) return rc;
+    if (e->opt.flags & STCSP_F_NO_EXPORT) {
+        memset(result, 0, sizeof *result);
+        result->truncated = e->truncated;
+        result->counters.seconds_search = e->seconds_search;
+        result->counters.levels = e->levels;
+        return STCSP_OK;
+    }
+    return e->export_result(result);
+}
+
+int stcsp_engine_export(stcsp_engine *e, stcsp_result *result) {
+    if (!e || !result) return STCSP_E_INVALID;
+    if (!e->begun) return e->fail(STCSP_E_STATE, "export before a solve");
+    return e->export_result(result);
+}
+
+void stcsp_engine_destroy(stcsp_engine *e) { delete e; }
+
+const char *stcsp_engine_last_error(const stcsp_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int stcsp_engine_begin(stcsp_engine *e) { return e ? e->begin() : STCSP_E_INVALID; }
+int stcsp_engine_expand_local(stcsp_engine *e, int64_t *left) { return e ? e->expand_local(left) : STCSP_E_INVALID; }
+int stcsp_engine_candidate_bytes(const stcsp_engine *e) { return e ? e->ctx.CS * 4 : STCSP_E_INVALID; }
+int stcsp_engine_outbox(stcsp_engine *e, int peer, void **ptr, int64_t *count) {
+    if (!e || !ptr || !count) return STCSP_E_INVALID;
+    return e->outbox(peer, ptr, count);
+}
+int stcsp_engine_commit(stcsp_engine *e, const void *records, int64_t count) { return e ? e->commit(records, count) : STCSP_E_INVALID; }
+int stcsp_engine_finish(stcsp_engine *e) { return e ? e->finish() : STCSP_E_INVALID; }
+
+}  // extern "C"

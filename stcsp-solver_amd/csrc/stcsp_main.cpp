@@ -1,0 +1,138 @@
+// stcsp_main.cpp -- the `stcsp` command line, functionally as the reference's
+// (src/stcsp.y:180-219 main, src/solver.cpp:195-359 solve): same flags, same stdout contract,
+// same solutions.dot. The search itself runs on the MI355X engine behind the C-ABI.
+//
+//   stcsp [-s] [-m<sec>] [-t] [-a] [-z] [-k<K>] [-l<level>] input.csp
+//
+// Options must be glued to their value (-k3, not -k 3): like the reference, the first argument
+// that does not start with '-' is the input file (stcsp.y:199-206).
+#include <sys/times.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "stcsp_engine.h"
+#include "stcsp_host.h"
+
+static double cpu_time() {  // cpuTime (util.cpp:149-155)
+    struct tms b;
+    times(&b);
+    return (double)(b.tms_utime + b.tms_stime + b.tms_cutime + b.tms_cstime) / (double)sysconf(_SC_CLK_TCK);
+}
+
+struct Flags {
+    bool print_solution = false, testing = false, adv1 = false, adv2 = false;
+    int prefix_k = 2, time_limit = 0;
+    const char *file = nullptr;
+};
+
+static int run_once(const Flags &f, bool print_line, double *total) {
+    double t_init = cpu_time();
+    stcsp_model *model = nullptr;
+    int rc = f.file ? stcsp_model_load_file(f.file, f.prefix_k, &model) : STCSP_E_INVALID;
+    if (rc != STCSP_OK) {
+        // syntax errors go to stdout like yyerror (stcsp.y:221-224); the rest to error.txt in the
+        // reference (myLog) -- stderr here
+        const char *msg = stcsp_host_last_error();
+        if (strncmp(msg, "Line ", 5) == 0)
+            printf("%s\n", msg);
+        else
+            fprintf(stderr, "%s\n", msg);
+        return 1;
+    }
+    const stcsp_problem *p = stcsp_model_problem(model);
+    double init_time = cpu_time() - t_init;
+    stcsp_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.world = 1;
+    opt.time_limit_s = f.time_limit;  // -m: the reference exit(0)s silently on SIGALRM (solver.cpp:190-193)
+    stcsp_engine *eng = nullptr;
+    rc = stcsp_engine_create(p, &opt, &eng);
+    if (rc != STCSP_OK) {
+        fprintf(stderr, "%s\n", stcsp_engine_last_error(nullptr));
+        return 1;
+    }
+    double t_solve = cpu_time();
+    stcsp_result res;
+    rc = stcsp_engine_solve(eng, &res);
+    if (rc != STCSP_OK) {
+        fprintf(stderr, "%s\n", stcsp_engine_last_error(eng));
+        return 1;
+    }
+    if (res.truncated) exit(0);  // time limit: silent exit 0, like the reference
+    double solve_time = cpu_time() - t_solve;
+    double t_proc = cpu_time();
+    stcsp_automaton *a = nullptr;
+    stcsp_automaton_build(p, &res, &a);
+    stcsp_automaton_traverse(a);                                             // solveralgorithm.cpp:974
+    if (f.adv1) printf("adver1: %d; ", stcsp_automaton_adversarial(a, 5));   // :975-978
+    if (f.adv2) printf("adver2: %d\n", stcsp_automaton_adversarial2(a, 5, 6)); // :980-983
+    stcsp_automaton_renumber(a);
+    double proc_time = cpu_time() - t_proc;
+    if (f.print_solution) stcsp_automaton_write_dot(a, "solutions.dot");
+    if (print_line) {
+        // init_time, var, con, dom, node, fail, solve_time, processTime (solveralgorithm.cpp:1001)
+        printf("%.2f\t%d\t%d\t%d\t%d\t%d\t%.2f\t%.5f\n", init_time, p->n_vars, p->n_constraints, (int)res.counters.dominance,
+               (int)res.n_states, (int)res.counters.fails, solve_time, proc_time);
+        fflush(stdout);
+    }
+    if (total) *total = solve_time + proc_time;
+    stcsp_automaton_free(a);
+    stcsp_engine_destroy(eng);
+    stcsp_model_free(model);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    Flags f;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (a[0] != '-') {
+            if (!f.file) f.file = a;
+            continue;
+        }
+        switch (a[1]) {
+            case 's': f.print_solution = true; break;
+            case 't': f.testing = true; break;
+            case 'a': f.adv1 = true; break;
+            case 'z': f.adv2 = true; break;
+            case 'k': f.prefix_k = atoi(a + 2); break;
+            case 'm': f.time_limit = atoi(a + 2); break;
+            case 'l': case 'b': case 'e': case 'v': break;  // parsed but unused in the reference too
+            default: fprintf(stderr, "Unknown argument: %c\n", a[1]); return 1;
+        }
+    }
+    if (!f.file) {
+        printf("No constraints!\n");
+        return 0;
+    }
+    int rc = run_once(f, !f.testing, nullptr);
+    if (rc) return rc;
+    if (f.testing) {  // -t: re-solve until the 95% CI half-width < 2.5% of the mean (solver.cpp:295-349)
+        std::vector<double> times;
+        for (;;) {
+            printf("%d ", (int)times.size());
+            fflush(stdout);
+            double t = 0;
+            if ((rc = run_once(f, true, &t))) return rc;
+            times.push_back(t);
+            size_t n = times.size();
+            if (n >= 10) {
+                double mean = 0, var = 0;
+                for (double x : times) mean += x;
+                mean /= n;
+                for (double x : times) var += (x - mean) * (x - mean);
+                var /= (n - 1);
+                if (2 * 1.96 * sqrt(var) / sqrt((double)n) < 0.05 * mean) {
+                    printf("\nMean execution time is %f pm %f\n", mean, 1.96 * sqrt(var) / sqrt((double)n));
+                    break;
+                }
+            }
+        }
+    }
+    return 0;
+}
