@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- search-tree nodes/sec of the MI355X engine on partialorder_14.csp.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one complete solve of the instance: propagation + search from the root until the
+whole automaton (state table + edge log) is resident in HBM.  The problem is already compiled
+and resident on the device when the timed region starts; copying the automaton to the host is
+NOT in `value` (it is reported as `export_ms`).  The unit is the search-tree node = one
+propagation-to-fixpoint + classification, the engine's analogue of one solverSolveRe call
+(reference src/solveralgorithm.cpp:733); each implementation counts its own tree.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     dominant kernel k_expand: algorithmic bytes per launch / average launch duration,
+               HIP events on the engine's stream, against the 8 TB/s HBM3E peak
+  cpu_baseline oracle/ref_dfs.cpp (the reference's algorithm restated, 1 thread) time-boxed on
+               the same instance on this box's host cores
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+WORKLOAD = "partialorder_14"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(st, name, seconds):
+    """Time-boxed run of the reference-faithful CPU restatement (kind = "port")."""
+    path = REPO / "oracle" / "libstcsp_oracle.so"
+    lib = C.CDLL(str(path))
+    st.bind_engine_api(lib, "stcsp_oracle")
+
+    class Ref(st.EngineBase):
+        _prefix = "stcsp_oracle"
+
+        def __init__(self, model, **o):
+            super().__init__(lib, model, **o)
+
+    m = st.Model.from_name(name)
+    o = Ref(m, time_limit_s=seconds)
+    t0 = time.time()
+    r = o.solve()
+    wall = time.time() - t0
+    nodes = r.counters.search_nodes
+    return {"value": nodes / wall, "unit": "search-tree nodes/s", "cores": 1, "kind": "port",
+            "sample": f"first {wall:.1f} s of the DFS on {name} ({nodes} nodes, "
+                      f"{'truncated' if r.truncated else 'complete'}); oracle/ref_dfs.cpp, 1 thread",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=WORKLOAD)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    st = importlib.import_module("stcsp-solver_amd")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    model = st.Model.from_name(args.workload)
+    flags = st.F_NO_EXPORT | st.F_PROFILE
+    eng = st.Engine(model, device=local_rank, rank=rank, world=world, flags=flags, batch_nodes=args.batch)
+
+    def one_step():
+        if world == 1:
+            eng.solve()
+        else:
+            from importlib import import_module
+            sh = import_module("stcsp-solver_amd.sharded")
+            sh.solve_sharded(eng, rank, world, dev)
+        return eng.counters()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    nodes = leaves = 0
+    k_time = 0.0
+    k_launches = 0
+    for _ in range(args.steps):
+        c = one_step()
+        nodes += c.search_nodes
+        leaves += c.leaves
+        k_time += c.seconds_expand_kernel
+        k_launches += c.expand_launches
+    barrier()
+    elapsed = time.perf_counter() - t0
+    levels = c.levels
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        t = torch.tensor([nodes, leaves], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        nodes, leaves = t.tolist()
+
+    # automaton export cost (PCIe D2H + ok-fixpoint), outside the timed region
+    export_ms = None
+    check = {}
+    if world == 1:
+        t1 = time.perf_counter()
+        res = eng.export()
+        export_ms = (time.perf_counter() - t1) * 1e3
+        a = eng.automaton(res).traverse().renumber()
+        check = {"states": a.n_live_states, "edges": a.n_live_edges, "canonical_sha256": a.canonical_sha256()}
+
+    if rank == 0:
+        p = model.problem.contents
+        N, K = p.n_vars, p.prefix_k
+        S = res.sig_len if world == 1 else 0
+        # B_node = 2*N*K*W*4 (read the parent block, write the child block)
+        # + per leaf: key probe + key store + edge record
+        b_node = 2 * N * K * 1 * 4
+        b_leaf = 4 * (S + 1) * 2 + 8 + 4 * N
+        alg_bytes = nodes * b_node + leaves * b_leaf
+        per_launch_bytes = alg_bytes / max(k_launches, 1)
+        avg_launch_s = k_time / max(k_launches, 1)
+        achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "search-tree nodes/sec on partialorder_14.csp",
+            "value": nodes / elapsed,
+            "unit": "search-tree nodes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}.csp (generated by stcsp-solver_amd/instances.py; "
+                                   f"{N} vars incl. aux, prefix K={K}, whole frontier resident in HBM)",
+                       "nodes_per_step": nodes // args.steps, "leaves_per_step": leaves // args.steps,
+                       "launch_rounds_per_step": int(levels), "sharding": "none" if world == 1 else f"state-owner x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_expand",
+                         "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,
+                         "launches": k_launches, "bytes_per_node": b_node, "bytes_per_leaf": b_leaf,
+                         "kernel_time_share": k_time / elapsed if elapsed > 0 else None},
+            "export_ms": export_ms,
+            "parity": check,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,7 @@ typedef struct stcsp_options {
 #define STCSP_F_KEEP_RAW_EDGES 1 /* also keep edges into failed states in the result (debug)       */
 #define STCSP_F_NO_EXPORT 2      /* solve() leaves the automaton on the device; call
                                     stcsp_engine_export() to copy it out (bench: HBM-resident)     */
+#define STCSP_F_PROFILE 4        /* bracket every k_expand launch with HIP events (roofline)       */
 
 typedef struct stcsp_counters {
     int64_t search_nodes; /* node expansions = propagation-to-fixpoint + classification; the
@@ -122,6 +123,10 @@ typedef struct stcsp_counters {
     int64_t levels;       /* engine only: kernel launch rounds                                     */
     double seconds_search;/* wall time of the search phase (automaton resident on device / in RAM) */
     double seconds_export;/* wall time of copying the automaton out + ok-fixpoint                  */
+    /* engine only, with STCSP_F_PROFILE: HIP-event time of the dominant kernel (k_expand), summed
+       over its launches, on the stream it is launched on */
+    double seconds_expand_kernel;
+    int64_t expand_launches;
 } stcsp_counters;
 
 /* The automaton as the search leaves it in solver->graph, before graphTraverse.
@@ -206,6 +211,13 @@ int stcsp_engine_candidate_bytes(const stcsp_engine *engine); /* record stride *
 int stcsp_engine_outbox(stcsp_engine *engine, int peer, void **device_ptr, int64_t *count);
 int stcsp_engine_commit(stcsp_engine *engine, const void *device_records, int64_t count);
 int stcsp_engine_finish(stcsp_engine *engine); /* closes the timed search phase */
+/* counters of the last / current solve without exporting the automaton */
+int stcsp_engine_counters(stcsp_engine *engine, stcsp_counters *out);
+/* Constraint-set registry exchange: every shard must know a set before it can open a state that
+ * uses it. sets_blob returns this shard's registry serialised as int32 words (valid until the
+ * next call); sets_import registers the sets of another shard's blob (idempotent). */
+int stcsp_engine_sets_blob(stcsp_engine *engine, const int32_t **words, int64_t *n_words);
+int stcsp_engine_sets_import(stcsp_engine *engine, const int32_t *words, int64_t n_words);
 
 #define STCSP_GID_SHIFT 40
 

@@ -488,6 +488,7 @@ thread_local std::string g_err;
 
 struct stcsp_fmodel {
     Model m;
+    std::vector<int32_t> blob;
     std::vector<std::vector<uint32_t>> handed;  // per peer: outbox buffer handed to the driver
 };
 
@@ -527,6 +528,37 @@ int stcsp_fmodel_outbox(stcsp_fmodel *h, int peer, void **ptr, int64_t *count) {
 int stcsp_fmodel_commit(stcsp_fmodel *h, const void *recs, int64_t count) { return h->m.commit((const uint32_t *)recs, count); }
 int stcsp_fmodel_finish(stcsp_fmodel *h) {
     h->m.ctr.seconds_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->m.t0).count();
+    return STCSP_OK;
+}
+int stcsp_fmodel_counters(stcsp_fmodel *h, stcsp_counters *out) {
+    *out = h->m.ctr;
+    return STCSP_OK;
+}
+int stcsp_fmodel_sets_blob(stcsp_fmodel *h, const int32_t **words, int64_t *n_words) {
+    h->blob.clear();
+    h->blob.push_back((int32_t)h->m.mgr.sets.size());
+    for (size_t i = 0; i < h->m.mgr.sets.size(); i++) {
+        std::vector<int32_t> w = h->m.mgr.serialise_set((int)i);
+        h->blob.push_back((int32_t)w.size());
+        h->blob.insert(h->blob.end(), w.begin(), w.end());
+    }
+    *words = h->blob.data();
+    *n_words = (int64_t)h->blob.size();
+    return STCSP_OK;
+}
+int stcsp_fmodel_sets_import(stcsp_fmodel *h, const int32_t *words, int64_t n) {
+    size_t before = h->m.mgr.sets.size();
+    int64_t pos = 1;
+    for (int32_t i = 0; i < words[0]; i++) {
+        int32_t len = words[pos++];
+        int rc = h->m.mgr.import_set(words + pos, (size_t)len);
+        if (rc < 0) {
+            h->m.err = h->m.mgr.error;
+            return rc;
+        }
+        pos += len;
+    }
+    if (h->m.mgr.sets.size() != before) return h->m.recompile();
     return STCSP_OK;
 }
 // Kernel-granularity check: propagate one domain block (N*K words, point-major) under

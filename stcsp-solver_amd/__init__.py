@@ -49,7 +49,8 @@ class Counters(C.Structure):
     _fields_ = [("search_nodes", C.c_int64), ("gac_calls", C.c_int64), ("fails", C.c_int64),
                 ("dominance", C.c_int64), ("leaves", C.c_int64), ("revisions", C.c_int64),
                 ("evaluations", C.c_int64), ("levels", C.c_int64),
-                ("seconds_search", C.c_double), ("seconds_export", C.c_double)]
+                ("seconds_search", C.c_double), ("seconds_export", C.c_double),
+                ("seconds_expand_kernel", C.c_double), ("expand_launches", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -70,12 +71,14 @@ class Result(C.Structure):
 
 F_KEEP_RAW_EDGES = 1
 F_NO_EXPORT = 2
+F_PROFILE = 4
 GID_SHIFT = 40
 
 ENGINE_SYMBOLS = [
     "stcsp_engine_create", "stcsp_engine_solve", "stcsp_engine_export", "stcsp_engine_destroy",
     "stcsp_engine_last_error", "stcsp_engine_begin", "stcsp_engine_expand_local",
     "stcsp_engine_candidate_bytes", "stcsp_engine_outbox", "stcsp_engine_commit", "stcsp_engine_finish",
+    "stcsp_engine_counters", "stcsp_engine_sets_blob", "stcsp_engine_sets_import",
 ]
 HOST_SYMBOLS = [
     "stcsp_model_load_file", "stcsp_model_load_text", "stcsp_model_problem", "stcsp_model_free",
@@ -168,6 +171,10 @@ def bind_engine_api(lib: C.CDLL, prefix: str = "stcsp_engine") -> None:
         g("outbox").argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         g("commit").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         g("finish").argtypes = [C.c_void_p]
+    if hasattr(lib, f"{prefix}_counters"):
+        g("counters").argtypes = [C.c_void_p, C.POINTER(Counters)]
+        g("sets_blob").argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64)]
+        g("sets_import").argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]
 
 
 def hip_lib() -> C.CDLL:
@@ -374,6 +381,22 @@ class EngineBase:
 
     def finish(self):
         self._check(self._f("finish")(self._h))
+
+    def counters(self) -> Counters:
+        c = Counters()
+        self._check(self._f("counters")(self._h, C.byref(c)))
+        return c
+
+    def sets_blob(self):
+        """This shard's constraint-set registry as a list of int32 words."""
+        p = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        self._check(self._f("sets_blob")(self._h, C.byref(p), C.byref(n)))
+        return [p[i] for i in range(n.value)]
+
+    def sets_import(self, words):
+        arr = (C.c_int32 * len(words))(*words)
+        self._check(self._f("sets_import")(self._h, arr, len(words)))
 
     def automaton(self, result: Result | None = None) -> Automaton:
         return Automaton(self._model, result if result is not None else self.result)

@@ -123,6 +123,13 @@ struct CommitArgs {
 };
 
 // ------------------------------------------------------------------ device helpers
+// The compiled program (bytecode, descriptors, tables) is read-only for the lifetime of a launch
+// and indexed wave-uniformly: reading it through the constant address space makes hipcc emit
+// scalar loads (s_load_dword through the scalar cache) instead of 64-lane vector loads.
+typedef const __attribute__((address_space(4))) int *kptr;
+__device__ __forceinline__ int kload(const void *base, int idx) {
+    return ((kptr)(const __attribute__((address_space(1))) int *)base)[idx];
+}
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -175,14 +182,14 @@ __device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uin
     bool valid = true;
     uint32_t dead = 0;
     for (;;) {
-        int w = rfl(c.code[pc++]);
+        int w = kload(c.code, pc++);
         int op = w & 255, arg = w >> 8;
         switch (op) {
             case OP_END: return t;
             case OP_CONST:
                 lds_stk[sp * 64 + lane] = t;
                 sp++;
-                t = rfl(c.code[pc++]);
+                t = kload(c.code, pc++);
                 break;
             case OP_VAR: {
                 lds_stk[sp * 64 + lane] = t;
@@ -195,7 +202,7 @@ __device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uin
                 break;
             }
             case OP_ARR: {
-                int off = rfl(c.arr_off[arg]), size = rfl(c.arr_off[arg + 1]) - off;
+                int off = kload(c.arr_off, arg), size = kload(c.arr_off, arg + 1) - off;
                 bool inr = (unsigned)t < (unsigned)size;
                 if (!inr && dead == 0) valid = false;
                 t = inr ? c.arr_data[off + t] : 0;
@@ -438,16 +445,14 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
 }
 
 __device__ __forceinline__ void load_set(const Ctx &c, int set, SetDesc &S) {
-    const int *src = (const int *)&c.sets[set];
     int *dst = (int *)&S;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = rfl(src[i]);
+    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = kload(c.sets, set * (int)(sizeof(SetDesc) / 4) + i);
 }
 __device__ __forceinline__ void load_con(const Ctx &c, int idx, ConDesc &C) {
-    const int *src = (const int *)&c.cons[idx];
     int *dst = (int *)&C;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = rfl(src[i]);
+    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = kload(c.cons, idx * (int)(sizeof(ConDesc) / 4) + i);
 }
 
 __device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
@@ -473,6 +478,10 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     const int gw = blockIdx.x * 4 + wib;
     const int r = gw % R, i = gw / R;
     if (i >= a.take[r]) return;
+    // outputs go to another cursor shard than the input's, or a subtree would stay in the region
+    // of its root forever; for every i exactly one input region maps to each output region, so
+    // an output region receives from at most max(take) wavefronts
+    const int ro = (i + r) % R;
     const int per_wave = (kMaxLowVars + c.stack_slots) * 64;
     int *lds_vals = smem + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
@@ -487,7 +496,13 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         dom.r[q] = idx < c.NK ? node[4 + idx] : 0u;
     }
     const uint32_t h0 = rflu(node[0]), h1 = rflu(node[1]);
-    const int set = rfl((int)node[2]);
+    // header word 2: constraint set (low 16 bits) | dirty seed (high 16 bits): 0 = revise every
+    // constraint (fresh state / root), 0xffff = nothing to revise (re-queued fixpoint), else
+    // 1 + the variable whose domain the parent just bisected -- the parent block was at its
+    // fixpoint, so only that variable's constraints can have lost supports
+    const uint32_t w2 = rflu(node[2]);
+    const int set = (int)(w2 & 0xffffu);
+    const uint32_t seed = w2 >> 16;
     const uint32_t expire = rflu(node[3]);
     SetDesc S;
     load_set(c, set, S);
@@ -498,8 +513,12 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     WaveStats ws;
     uint32_t dirtyw = 0;
     if (lane < S.cw) {
-        int left = S.ncons - lane * 32;
-        dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+        if (seed == 0) {
+            int left = S.ncons - lane * 32;
+            dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+        } else if (seed != 0xffffu) {
+            dirtyw = c.varcons[S.varcons_off + (int)(seed - 1) * S.cw + lane];
+        }
     }
     bool consistent = true;
     unsigned guard = 0;
@@ -515,7 +534,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         load_con(c, S.con_begin + ci, C);
         if (C.type == CT_NEXT) {
             // X == next Y  <=>  X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
-            int sh = rfl(c.var_lb[C.x]) - rfl(c.var_lb[C.y]);
+            int sh = kload(c.var_lb, C.x) - kload(c.var_lb, C.y);
             for (int p = 0; p + 1 < c.K && consistent; p++) {
                 int ix = p * c.N + C.x, iy = (p + 1) * c.N + C.y;
                 uint32_t DX = dom.get(ix), DY = dom.get(iy);
@@ -543,7 +562,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
             if (!((expire >> C.until_ordinal) & 1u)) {
                 uint32_t DX = dom.get(C.x), DY = dom.get(C.y);
                 if (__popc(DX) == 1 && __popc(DY) == 1) {
-                    int vx = rfl(c.var_lb[C.x]) + __ffs((int)DX) - 1, vy = rfl(c.var_lb[C.y]) + __ffs((int)DY) - 1;
+                    int vx = kload(c.var_lb, C.x) + __ffs((int)DX) - 1, vy = kload(c.var_lb, C.y) + __ffs((int)DY) - 1;
                     if (vx != 1 && vy != 1) consistent = false;
                 }
             }
@@ -573,7 +592,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         unsigned long long m = __ballot(idx < c.N && __popc(dom.r[q]) > 1);
         if (bvar < 0 && m) bvar = q * 64 + __ffsll((long long)m) - 1;
     }
-    uint32_t *out_region = a.out_base + (size_t)r * a.out_cap * c.NS;
+    uint32_t *out_region = a.out_base + (size_t)ro * a.out_cap * c.NS;
     if (bvar >= 0) {
         // bisect [lb,ub] of the branching variable (variableSplitLower/Upper, variable.cpp:52-67)
         uint32_t D = dom.get(bvar);
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         int mid = lo + (hi - lo) / 2;
         uint32_t lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
         uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + r * CST], 2u);
+        if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + ro * CST], 2u);
         pos = rflu(pos);
         if (pos + 2 > a.out_cap) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -589,9 +608,10 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         }
         Dom<DR> child = dom;
         child.set(bvar, D & lowmask, lane);
-        store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set, expire, child, lane);
+        const uint32_t cw2 = (uint32_t)set | ((uint32_t)(bvar + 1) << 16);
+        store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, cw2, expire, child, lane);
         child.set(bvar, D & ~lowmask, lane);
-        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, h0, h1, (uint32_t)set, expire, child, lane);
+        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, h0, h1, cw2, expire, child, lane);
         return;
     }
 
@@ -626,13 +646,13 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
             uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + r * CST], 1u);
+            if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + ro * CST], 1u);
             pos = rflu(pos);
             if (pos + 1 > a.out_cap) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
                 return;
             }
-            store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set, expire, dom, lane);
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set | 0xffff0000u, expire, dom, lane);
             if (lane == 0) add_stats(c, gw, ST_REQUEUE, 1);
             return;
         }
@@ -665,13 +685,13 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     const int owner = (int)((h >> 40) % (unsigned)c.world);
     // (4) candidate record: header, signature, edge label, time-advanced block
     uint32_t pos = 0;
-    if (lane == 0) pos = atomicAdd(&c.ctl[L.cand0 + (owner * R + r) * CST], 1u);
+    if (lane == 0) pos = atomicAdd(&c.ctl[L.cand0 + (owner * R + ro) * CST], 1u);
     pos = rflu(pos);
     if (pos + 1 > a.cand_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
         return;
     }
-    uint32_t *rec = a.cand_base + ((size_t)(owner * R + r) * a.cand_cap + pos) * c.CS;
+    uint32_t *rec = a.cand_base + ((size_t)(owner * R + ro) * a.cand_cap + pos) * c.CS;
     if (lane < 4) rec[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? next_tag : new_expire));
     if (lane >= 1 && lane <= c.sig_len) rec[4 + lane - 1] = kw;
     uint32_t *vals = rec + 4 + c.sig_len;
@@ -702,11 +722,13 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     const CtlLayout L(c.world);
     uint32_t *misc = c.ctl + L.misc0;
     const uint32_t *rec;
+    int ro = r;  // cursor shard for this wavefront's outputs (edge record, new node)
     if (a.regions) {
         long long i = gw / R;
         uint32_t cnt = c.ctl[a.cand_cursor_base + r * CST];
         if (i >= (long long)cnt) return;
         rec = a.cand_base + ((size_t)r * a.cand_cap + (size_t)i) * c.CS;
+        ro = (int)((i + r) % R);
     } else {
         if (gw >= a.total) return;
         rec = a.cand_base + (size_t)gw * c.CS;
@@ -783,13 +805,13 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     }
     // edge record: src (global id), dst (local index), label = time-0 value of every variable
     uint32_t e = 0;
-    if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + r * CST], 1u);
+    if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + ro * CST], 1u);
     e = rflu(e);
     if (e >= c.edge_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_EDGE_OVERFLOW);
         return;
     }
-    uint32_t *er = c.edges + ((size_t)r * c.edge_cap + e) * c.ES;
+    uint32_t *er = c.edges + ((size_t)ro * c.edge_cap + e) * c.ES;
     if (lane < 4) er[lane] = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? idx : 0u));
     const uint32_t *vals = rec + 4 + c.sig_len;
     for (int v = lane; v < c.N; v += 64) er[4 + v] = vals[v];
@@ -803,13 +825,13 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
         return;
     }
     uint32_t np = 0;
-    if (lane == 0) np = atomicAdd(&c.ctl[L.out0 + r * CST], 1u);
+    if (lane == 0) np = atomicAdd(&c.ctl[L.out0 + ro * CST], 1u);
     np = rflu(np);
     if (np + 1 > a.out_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
         return;
     }
-    uint32_t *dst = a.out_base + ((size_t)r * a.out_cap + np) * c.NS;
+    uint32_t *dst = a.out_base + ((size_t)ro * a.out_cap + np) * c.NS;
     const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | idx;
     if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)set : expire));
     const uint32_t *blk = vals + c.N;
@@ -922,6 +944,12 @@ struct stcsp_engine {
     double seconds_search = 0, seconds_export = 0;
     long long levels = 0;
     std::string err;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double seconds_expand_kernel = 0;
+    long long expand_launches = 0;
+    stcsp_counters snap{};
+    std::vector<int32_t> blob;
 
     // export storage
     std::vector<int32_t> r_cid, r_sig, r_eval;
@@ -929,6 +957,10 @@ struct stcsp_engine {
     std::vector<int64_t> r_esrc, r_edst;
 
     ~stcsp_engine() {
+        for (auto &e : ev_pool) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_miss) (void)hipHostFree(h_miss);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1141,6 +1173,9 @@ struct stcsp_engine {
         truncated = false;
         levels = 0;
         finished = false;
+        ev_used = 0;
+        seconds_expand_kernel = 0;
+        expand_launches = 0;
         HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
@@ -1236,7 +1271,7 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         Segment T{};
         T.base = arena_top;
-        T.cap = (uint32_t)(2 * maxtake);
+        T.cap = (uint32_t)(3 * maxtake);
         rc = ensure_arena((size_t)R * T.cap * ctx.NS);
         if (rc != STCSP_OK) return rc;
         // zero the out cursors (and, unsharded, the outbox cursors): contiguous at the start of ctl
@@ -1248,12 +1283,24 @@ struct stcsp_engine {
         a.out_cap = T.cap;
         a.cand_base = d_cand.p;
         a.cand_cap = cand_cap;
+        const bool prof = opt.flags & STCSP_F_PROFILE;
+        if (prof) {
+            if (ev_used == ev_pool.size()) {
+                hipEvent_t e0, e1;
+                HIPCHK(hipEventCreate(&e0));
+                HIPCHK(hipEventCreate(&e1));
+                ev_pool.emplace_back(e0, e1);
+            }
+            HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+        }
         switch (DR) {
             case 1: launch_expand<1>(a, maxtake); break;
             case 2: launch_expand<2>(a, maxtake); break;
             default: launch_expand<4>(a, maxtake); break;
         }
         HIPCHK(hipGetLastError());
+        if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
+        expand_launches++;
         if (commit_local) {
             CommitArgs ca{};
             ca.cand_base = d_cand.p;
@@ -1319,11 +1366,36 @@ struct stcsp_engine {
         return finish();
     }
 
+    int read_counters(stcsp_counters &ctr) {
+        std::vector<unsigned long long> st(kStatSlots * kStatWords);
+        HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long tot[kStatWords] = {0};
+        for (int s = 0; s < kStatSlots; s++)
+            for (int k = 0; k < kStatWords; k++) tot[k] += st[s * kStatWords + k];
+        ctr = stcsp_counters{};
+        ctr.search_nodes = (int64_t)(tot[ST_NODES] - tot[ST_REQUEUE]);
+        ctr.gac_calls = (int64_t)tot[ST_NODES];
+        ctr.fails = (int64_t)tot[ST_FAILS];
+        ctr.leaves = (int64_t)tot[ST_LEAVES];
+        ctr.revisions = (int64_t)tot[ST_REVS];
+        ctr.evaluations = (int64_t)tot[ST_EVALS];
+        ctr.levels = levels;
+        ctr.seconds_search = finished ? seconds_search : elapsed();
+        ctr.seconds_expand_kernel = seconds_expand_kernel;
+        ctr.expand_launches = expand_launches;
+        return STCSP_OK;
+    }
     int finish() {
         HIPCHK(hipStreamSynchronize(stream));
         seconds_search = elapsed();
         finished = true;
-        return STCSP_OK;
+        for (size_t i = 0; i < ev_used; i++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+            seconds_expand_kernel += ms * 1e-3;
+        }
+        ev_used = 0;
+        return read_counters(snap);
     }
 
     // ---- sharded stepping
@@ -1440,21 +1512,11 @@ struct stcsp_engine {
                 memcpy(&r_eval[e * N], er + 4, (size_t)N * sizeof(int32_t));
             }
         }
-        // counters
-        std::vector<unsigned long long> st(kStatSlots * kStatWords);
-        HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long tot[kStatWords] = {0};
-        for (int s = 0; s < kStatSlots; s++)
-            for (int k = 0; k < kStatWords; k++) tot[k] += st[s * kStatWords + k];
         stcsp_counters ctr{};
-        ctr.search_nodes = (int64_t)(tot[ST_NODES] - tot[ST_REQUEUE]);
-        ctr.gac_calls = (int64_t)tot[ST_NODES];
-        ctr.fails = (int64_t)tot[ST_FAILS];
-        ctr.leaves = (int64_t)tot[ST_LEAVES];
-        ctr.revisions = (int64_t)tot[ST_REVS];
-        ctr.evaluations = (int64_t)tot[ST_EVALS];
-        ctr.levels = levels;
-        ctr.seconds_search = seconds_search;
+        {
+            int rcc = read_counters(ctr);
+            if (rcc != STCSP_OK) return rcc;
+        }
         r_fail.assign(n_states, 0);
         if (opt.world == 1) {
             // ok-fixpoint over the raw leaf-edge log (okfix.hpp); sharded runs do it after the merge
@@ -1531,8 +1593,7 @@ int stcsp_engine_solve(stcsp_engine *e, stcsp_result *result) {
     if (e->opt.flags & STCSP_F_NO_EXPORT) {
         memset(result, 0, sizeof *result);
         result->truncated = e->truncated;
-        result->counters.seconds_search = e->seconds_search;
-        result->counters.levels = e->levels;
+        result->counters = e->snap;
         return STCSP_OK;
     }
     return e->export_result(result);
@@ -1557,5 +1618,38 @@ int stcsp_engine_outbox(stcsp_engine *e, int peer, void **ptr, int64_t *count) {
 }
 int stcsp_engine_commit(stcsp_engine *e, const void *records, int64_t count) { return e ? e->commit(records, count) : STCSP_E_INVALID; }
 int stcsp_engine_finish(stcsp_engine *e) { return e ? e->finish() : STCSP_E_INVALID; }
+int stcsp_engine_counters(stcsp_engine *e, stcsp_counters *out) {
+    if (!e || !out) return STCSP_E_INVALID;
+    if (!e->begun) return e->fail(STCSP_E_STATE, "counters before a solve");
+    return e->read_counters(*out);
+}
+int stcsp_engine_sets_blob(stcsp_engine *e, const int32_t **words, int64_t *n_words) {
+    if (!e || !words || !n_words) return STCSP_E_INVALID;
+    e->blob.clear();
+    e->blob.push_back((int32_t)e->mgr.sets.size());
+    for (size_t i = 0; i < e->mgr.sets.size(); i++) {
+        std::vector<int32_t> w = e->mgr.serialise_set((int)i);
+        e->blob.push_back((int32_t)w.size());
+        e->blob.insert(e->blob.end(), w.begin(), w.end());
+    }
+    *words = e->blob.data();
+    *n_words = (int64_t)e->blob.size();
+    return STCSP_OK;
+}
+int stcsp_engine_sets_import(stcsp_engine *e, const int32_t *words, int64_t n) {
+    if (!e || !words || n < 1) return STCSP_E_INVALID;
+    size_t before = e->mgr.sets.size();
+    int64_t pos = 1;
+    for (int32_t i = 0; i < words[0]; i++) {
+        if (pos >= n) return e->fail(STCSP_E_INVALID, "truncated set blob");
+        int32_t len = words[pos++];
+        if (pos + len > n) return e->fail(STCSP_E_INVALID, "truncated set blob");
+        int rc = e->mgr.import_set(words + pos, (size_t)len);
+        if (rc < 0) return e->fail(rc, "%s", e->mgr.error.c_str());
+        pos += len;
+    }
+    if (e->mgr.sets.size() != before) return e->upload_program();
+    return STCSP_OK;
+}
 
 }  // extern "C"
