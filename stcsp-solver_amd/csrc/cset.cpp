@@ -403,8 +403,146 @@ int SetManager::compile_expr(const Tree *t, const std::vector<int> &scope, bool 
     return STCSP_OK;
 }
 
+// Host evaluation of a constraint tree on one tuple (scope position -> value): the semantics of
+// solverValidateRe (reference src/solveralgorithm.cpp:336-424), used to tabulate constraints.
+int SetManager::eval_tree(const Tree *t, const std::vector<int> &scope, const int *vals, bool &valid) const {
+    if (!t) return 0;
+    switch (t->token) {
+        case STCSP_T_VAR: return vals[std::find(scope.begin(), scope.end(), t->var) - scope.begin()];
+        case STCSP_T_CONST: return t->num;
+        case STCSP_T_ARR: {
+            int i = eval_tree(t->right, scope, vals, valid);
+            const std::vector<int> &a = arrays.elements[t->arr];
+            if (i < 0 || i >= (int)a.size()) {
+                valid = false;
+                return 0;
+            }
+            return a[i];
+        }
+        case STCSP_T_ABS: {
+            int v = eval_tree(t->right, scope, vals, valid);
+            return v < 0 ? (int)(0u - (unsigned)v) : v;
+        }
+        case STCSP_T_IF:
+            return eval_tree(t->left, scope, vals, valid) ? eval_tree(t->right->left, scope, vals, valid)
+                                                          : eval_tree(t->right->right, scope, vals, valid);
+        case STCSP_T_FIRST: return eval_tree(t->right, scope, vals, valid);
+        case STCSP_T_AT: return eval_tree(t->left, scope, vals, valid);
+        case STCSP_T_NOT: return eval_tree(t->right, scope, vals, valid) == 0;
+        case STCSP_T_AND: return eval_tree(t->left, scope, vals, valid) ? eval_tree(t->right, scope, vals, valid) : 0;
+        case STCSP_T_OR: return eval_tree(t->left, scope, vals, valid) ? 1 : eval_tree(t->right, scope, vals, valid);
+        case STCSP_T_IMPLY_CON: {
+            int l = eval_tree(t->left, scope, vals, valid);
+            return l == 0 ? 1 : (l <= eval_tree(t->right, scope, vals, valid));
+        }
+        default: break;
+    }
+    int l = eval_tree(t->left, scope, vals, valid);
+    int r = eval_tree(t->right, scope, vals, valid);
+    if (!valid) return 0;
+    switch (t->token) {
+        case STCSP_T_LT_CON: case STCSP_T_LT_OP: return l < r;
+        case STCSP_T_GT_CON: case STCSP_T_GT_OP: return l > r;
+        case STCSP_T_LE_CON: case STCSP_T_LE_OP: return l <= r;
+        case STCSP_T_GE_CON: case STCSP_T_GE_OP: return l >= r;
+        case STCSP_T_EQ_CON: case STCSP_T_EQ_OP: return l == r;
+        case STCSP_T_NE_CON: case STCSP_T_NE_OP: return l != r;
+        case STCSP_T_ADD: return (int)((unsigned)l + (unsigned)r);
+        case STCSP_T_SUB: return (int)((unsigned)l - (unsigned)r);
+        case STCSP_T_MUL: return (int)((unsigned)l * (unsigned)r);
+        case STCSP_T_DIV: return (r == 0 || (l == INT32_MIN && r == -1)) ? 0 : l / r;
+        case STCSP_T_MOD: return (r == 0 || (l == INT32_MIN && r == -1)) ? 0 : l % r;
+        default: return 0;
+    }
+}
+
+// Tabulate a point constraint over the product of its variables' INITIAL domains.
+//   small  (arity <= 4, <= kSmallMaxRows rows): one 32-bit row of allowed values of the "word"
+//          variable (the widest one) per tuple of the other variables -- one lane revises it;
+//   bitmap (product <= kBitmapMaxBits): one bit per tuple -- the wavefront revises it with a
+//          lookup in place of interpreting the postfix program;
+//   otherwise the program is interpreted.
+void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, std::vector<ItemDesc> &small, bool &is_small) {
+    is_small = false;
+    cd.bitmap_off = -1;
+    cd.stride_off = 0;
+    const int s = (int)c.scope.size();
+    if (c.type != CT_POINT || s == 0) return;
+    std::vector<int> size(s);
+    long long product = 1;
+    for (int j = 0; j < s; j++) {
+        size[j] = ub[c.scope[j]] - lb[c.scope[j]] + 1;
+        product *= size[j];
+        if (product > kBitmapMaxBits) return;
+    }
+    std::vector<int> vals(s), bit(s, 0);
+    auto holds = [&]() {
+        for (int j = 0; j < s; j++) vals[j] = lb[c.scope[j]] + bit[j];
+        bool valid = true;
+        return eval_tree(c.root, c.scope, vals.data(), valid) != 0;
+    };
+    int w = 0;
+    for (int j = 1; j < s; j++)
+        if (size[j] > size[w]) w = j;
+    long long rows = product / size[w];
+    if (s <= 4 && rows <= kSmallMaxRows) {
+        std::vector<int> others;
+        for (int j = 0; j < s; j++)
+            if (j != w) others.push_back(j);
+        ItemDesc it{};
+        it.type = IT_SMALL;
+        it.arity = s;
+        it.toff = (int32_t)out.tables.size();
+        it.r1 = others.size() > 0 ? size[others[0]] : 1;
+        it.r2 = others.size() > 1 ? size[others[1]] : 1;
+        int r3 = others.size() > 2 ? size[others[2]] : 1;
+        // idx[] carries scope positions here; the caller turns them into block word indices
+        it.idx[0] = w;
+        for (size_t k = 0; k < 3; k++) it.idx[1 + k] = k < others.size() ? others[k] : -1;
+        for (int b3 = 0; b3 < r3; b3++)
+            for (int b2 = 0; b2 < it.r2; b2++)
+                for (int b1 = 0; b1 < it.r1; b1++) {
+                    if (others.size() > 0) bit[others[0]] = b1;
+                    if (others.size() > 1) bit[others[1]] = b2;
+                    if (others.size() > 2) bit[others[2]] = b3;
+                    uint32_t row = 0;
+                    for (int b0 = 0; b0 < size[w]; b0++) {
+                        bit[w] = b0;
+                        if (holds()) row |= 1u << b0;
+                    }
+                    out.tables.push_back(row);
+                }
+        small.push_back(it);
+        is_small = true;
+        return;
+    }
+    cd.stride_off = (int32_t)out.strides.size();
+    long long st = 1;
+    for (int j = 0; j < s; j++) {
+        out.strides.push_back((int32_t)st);
+        st *= size[j];
+    }
+    cd.bitmap_off = (int32_t)out.tables.size();
+    out.tables.resize(out.tables.size() + (size_t)((product + 31) / 32), 0u);
+    uint32_t *bm = out.tables.data() + cd.bitmap_off;
+    for (long long t = 0; t < product; t++) {
+        long long rem = t;
+        for (int j = 0; j < s; j++) {
+            bit[j] = (int)(rem % size[j]);
+            rem /= size[j];
+        }
+        if (holds()) bm[t >> 5] |= 1u << (t & 31);
+    }
+}
+
 int SetManager::compile(FlatProgram &out) {
     out = FlatProgram();
+    struct TableCacheEntry {
+        int32_t bitmap_off, stride_off;
+        bool is_small;
+        ItemDesc small;
+    };
+    std::map<std::vector<int32_t>, TableCacheEntry> table_cache;
     for (size_t si = 0; si < sets.size(); si++) {
         HostSet &s = *sets[si];
         SetDesc sd{};
@@ -435,6 +573,7 @@ int SetManager::compile(FlatProgram &out) {
             out.trans.push_back(td);
         }
         sd.tag = s.tag;
+        std::vector<ItemDesc> small_items, wave_items;
         for (size_t ci = 0; ci < s.cons.size(); ci++) {
             HostCon &c = s.cons[ci];
             ConDesc cd{};
@@ -461,9 +600,90 @@ int SetManager::compile(FlatProgram &out) {
                 if (max_depth > out.max_stack) out.max_stack = max_depth;
             }
             cd.code_len = (int32_t)out.code.size() - cd.code_off;
+            // work items of this constraint (one per enforced time point)
+            const int con_abs = (int)out.cons.size();
+            if (c.type == CT_NEXT) {
+                for (int p = 0; p + 1 < K; p++) {
+                    ItemDesc it{};
+                    it.type = IT_NEXT;
+                    it.point = p;
+                    it.con = con_abs;
+                    it.arity = 2;
+                    it.idx[0] = p * N + c.x;
+                    it.idx[1] = (p + 1) * N + c.y;
+                    it.aux = lb[c.x] - lb[c.y];
+                    small_items.push_back(it);
+                }
+            } else if (c.type == CT_UNTIL) {
+                ItemDesc it{};
+                it.type = IT_UNTIL;
+                it.con = con_abs;
+                it.arity = 2;
+                it.idx[0] = c.x;
+                it.idx[1] = c.y;
+                it.aux = c.until_ordinal;
+                small_items.push_back(it);
+            } else if (c.type == CT_POINT && !c.scope.empty()) {
+                // identical constraints (e.g. the same constraint in two sets) share their tables
+                std::vector<int32_t> key;
+                serialise_tree(c.root, key);
+                auto hit = table_cache.find(key);
+                std::vector<ItemDesc> proto;
+                bool is_small = false;
+                if (hit != table_cache.end()) {
+                    cd.bitmap_off = hit->second.bitmap_off;
+                    cd.stride_off = hit->second.stride_off;
+                    is_small = hit->second.is_small;
+                    if (is_small) proto.push_back(hit->second.small);
+                } else {
+                    build_tables(c, cd, out, proto, is_small);
+                    TableCacheEntry e{cd.bitmap_off, cd.stride_off, is_small, is_small ? proto[0] : ItemDesc{}};
+                    table_cache.emplace(key, e);
+                }
+                for (int p = 0; p < cd.npoints; p++) {
+                    ItemDesc it{};
+                    if (is_small) {
+                        it = proto[0];
+                        for (int k = 0; k < 4; k++) it.idx[k] = it.idx[k] >= 0 ? p * N + c.scope[it.idx[k]] : 0;
+                    } else {
+                        it.type = IT_WAVE;
+                        it.arity = cd.scope_len;
+                    }
+                    it.point = p;
+                    it.con = con_abs;
+                    (is_small ? small_items : wave_items).push_back(it);
+                }
+            } else {
+                cd.bitmap_off = -1;
+            }
             out.cons.push_back(cd);
             if (c.type != CT_AT)  // AT constraints are never revised (solveralgorithm.cpp:658-662)
                 for (int v : c.scope) out.varcons[sd.varcons_off + (size_t)v * sd.cw + ci / 32] |= 1u << (ci % 32);
+        }
+        // items: lane-revised ones first, then the wavefront-revised ones
+        sd.item_begin = (int32_t)out.items.size();
+        sd.nsmall = (int32_t)small_items.size();
+        sd.nitems = (int32_t)(small_items.size() + wave_items.size());
+        sd.iw = std::max(1, (sd.nitems + 31) / 32);
+        if (sd.iw > 64) {
+            error = "more than 2048 propagation items in one set";
+            return STCSP_E_UNSUPPORTED;
+        }
+        if (sd.iw > out.max_iw) out.max_iw = sd.iw;
+        out.items.insert(out.items.end(), small_items.begin(), small_items.end());
+        out.items.insert(out.items.end(), wave_items.begin(), wave_items.end());
+        sd.itemrows_off = (int32_t)out.itemrows.size();
+        out.itemrows.resize(out.itemrows.size() + (size_t)N * K * sd.iw, 0u);
+        for (int i = 0; i < sd.nitems; i++) {
+            const ItemDesc &it = out.items[sd.item_begin + i];
+            auto mark = [&](int word) { out.itemrows[sd.itemrows_off + (size_t)word * sd.iw + i / 32] |= 1u << (i % 32); };
+            if (it.type == IT_NEXT || it.type == IT_UNTIL) {
+                mark(it.idx[0]);
+                mark(it.idx[1]);
+            } else {
+                const ConDesc &cd = out.cons[it.con];
+                for (int j = 0; j < cd.scope_len; j++) mark(it.point * N + out.scope[cd.scope_off + j]);
+            }
         }
         out.sets.push_back(sd);
     }

@@ -45,8 +45,12 @@ struct FlatProgram {
     std::vector<int32_t> scope, code, firstvars, transvals;
     std::vector<uint32_t> varcons;
     std::vector<TransDesc> trans;
+    std::vector<ItemDesc> items;
+    std::vector<uint32_t> itemrows, tables;
+    std::vector<int32_t> strides;
     int max_stack = 1;
     int max_cw = 1;
+    int max_iw = 1;
 };
 
 class SetManager {
@@ -79,6 +83,8 @@ private:
     int register_set(std::unique_ptr<HostSet> s);
     Tree *translate(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
     Tree *translate_first(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
+    int eval_tree(const Tree *t, const std::vector<int> &scope, const int *vals, bool &valid) const;
+    void build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, std::vector<ItemDesc> &small, bool &is_small);
     int compile_expr(const Tree *t, const std::vector<int> &scope, bool guards, std::vector<int32_t> &code, int &depth,
                      int &max_depth, int &mask_depth);
 };

@@ -20,6 +20,8 @@ constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revis
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
+constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
+constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap compiled per constraint
 
 enum ConType : int32_t { CT_NEXT = 0, CT_POINT = 1, CT_UNTIL = 2, CT_AT = 3 };
 
@@ -61,7 +63,24 @@ struct ConDesc {          // one constraint of one constraint set
     int32_t x, y;         // NEXT: X == next Y ; UNTIL: X until Y
     int32_t until_ordinal;
     int32_t uses_valid;   // program contains array lookups => track `valid` + liveness
-    int32_t pad0, pad1;
+    int32_t bitmap_off;   // >= 0: into tables[], satisfying-tuple bitmap over the full initial
+                          //       product (bit index = sum_j bitpos_j * stride_j); -1: interpret code
+    int32_t stride_off;   // into strides[] (parallel to the scope) when bitmap_off >= 0
+};
+
+// A propagation work item = one constraint at one time point. Items are what the dirty mask
+// tracks; items [0, nsmall) of a set are "small" (one lane revises one item), the rest are
+// revised by the whole wavefront.
+enum ItemType : int32_t { IT_NEXT = 0, IT_UNTIL = 1, IT_SMALL = 2, IT_WAVE = 3 };
+struct ItemDesc {
+    int32_t type;
+    int32_t point;
+    int32_t con;          // index into cons[] (absolute)
+    int32_t arity;        // IT_SMALL: 1..4 (word variable first)
+    int32_t idx[4];       // block word indices p*N+v.  NEXT: idx[0] = (p,X), idx[1] = (p+1,Y)
+    int32_t toff;         // IT_SMALL: into tables[], one 32-bit row per tuple of variables 1..3
+    int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2
+    int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal
 };
 
 struct SetDesc {          // one constraint set (entry of Solver::seenConstraints)
@@ -75,7 +94,12 @@ struct SetDesc {          // one constraint set (entry of Solver::seenConstraint
     int32_t trans_begin;  // into trans[]: known (values -> next set) transitions of this set
     int32_t trans_count;
     int32_t tag;          // id stored in state keys (ordinal when unsharded, content hash when sharded)
-    int32_t pad0, pad1;
+    int32_t item_begin;   // into items[]
+    int32_t nitems;
+    int32_t nsmall;       // items [0, nsmall) are lane-revised
+    int32_t iw;           // dirty-mask words = (nitems + 31) / 32
+    int32_t itemrows_off; // into itemrows[]: [N*K][iw] rows: items that read block word (p,v)
+    int32_t pad0;
 };
 
 struct TransDesc {

@@ -89,6 +89,10 @@ struct Ctx {
     const TransDesc *trans;
     const int *transvals;
     const uint32_t *varcons;
+    const ItemDesc *items;
+    const uint32_t *itemrows;
+    const uint32_t *tables;
+    const int *strides;
     unsigned long long *slots;
     uint32_t slot_mask;
     uint32_t *state_keys;
@@ -266,8 +270,14 @@ __device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uin
 // scope variable has a supporting tuple (generalised arc consistency on this constraint; the
 // reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
 // Returns false when a domain is wiped out. `dirty` rows of changed variables are OR-ed in.
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 template <int DR>
-__device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, int ci, int p, Dom<DR> &dom, int lane,
+__device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom, int lane,
                              uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
@@ -281,6 +291,9 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
     int n = lane < s ? __popc(D) : 1;
     if (__ballot(lane < s && n == 0)) return false;
     int vlb = lane < s ? c.var_lb[var] : 0;
+    const bool use_bitmap = C.bitmap_off >= 0;
+    const int mystride = (use_bitmap && lane < s) ? c.strides[C.stride_off + lane] : 0;
+    int lane_part = 0;  // bitmap: this lane's tuple index contribution of the lane-enumerated variables
 
     // --- split the scope: up to kMaxLowVars variables whose domain sizes multiply to <= 64 are
     // enumerated ACROSS LANES (lane index = mixed-radix tuple index); the rest are wave-uniform
@@ -322,7 +335,9 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
             int lbj = (int)rdlane((uint32_t)vlb, j);
             int pb = (int)rdlane((uint32_t)pairbase, j);
             int digit = (lane / st) % nj;
-            lds_vals[slot * 64 + lane] = lbj + select_kth(Dj, digit);
+            int bitpos = select_kth(Dj, digit);
+            lds_vals[slot * 64 + lane] = lbj + bitpos;
+            if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
             for (int k = 0; k < nj; k++) {
                 unsigned long long m = __ballot(active && digit == k);
                 if (lane == pb + k) {
@@ -375,7 +390,13 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
                 curval = vlb + curbit;
             }
         }
-        int res = eval_program(c, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        int res;
+        if (use_bitmap) {
+            int bit = lane_part + wave_sum(is_uniform ? curbit * mystride : 0);
+            res = active ? (int)((c.tables[C.bitmap_off + (bit >> 5)] >> (bit & 31)) & 1u) : 0;
+        } else {
+            res = eval_program(c, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        }
         ws.evals += nact;
         unsigned long long sm = __ballot(active && res != 0);
         if (pairlane && ((((unsigned long long)Mhi << 32) | Mlo) & sm)) hit = true;
@@ -435,12 +456,12 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
         if (newD != Dj) {
             int vj = (int)rdlane((uint32_t)var, j);
             dom.set(p * c.N + vj, newD, lane);
-            if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + vj * S.cw + lane];
+            if (lane < S.iw) dirtyw |= c.itemrows[S.itemrows_off + (p * c.N + vj) * S.iw + lane];
         }
     }
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
     // its own changes (supports are whole tuples of surviving values)
-    if (lane == (ci >> 5)) dirtyw &= ~(1u << (ci & 31));
+    if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
     return ok;
 }
 
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     // of its root forever; for every i exactly one input region maps to each output region, so
     // an output region receives from at most max(take) wavefronts
     const int ro = (i + r) % R;
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64;
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
     int *lds_vals = smem + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     const CtlLayout L(c.world);
@@ -507,67 +528,149 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     SetDesc S;
     load_set(c, set, S);
 
-    // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). The
-    // schedule is a dirty bitmask over the set's constraints (lane w holds word w); the fixpoint
-    // of monotone propagators does not depend on the order.
+    // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). Work items
+    // are (constraint, time point) pairs; the dirty mask is lane-striped (lane w holds word w).
+    // Items [0, nsmall) -- X == next Y arcs, until checks and small extensional point constraints --
+    // are revised ONE ITEM PER LANE against a snapshot of the block, their prunings ANDed together
+    // through an LDS copy (a Jacobi sweep); the remaining items are revised by the whole
+    // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
     WaveStats ws;
+    int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
     uint32_t dirtyw = 0;
-    if (lane < S.cw) {
+    if (lane < S.iw) {
         if (seed == 0) {
-            int left = S.ncons - lane * 32;
+            int left = S.nitems - lane * 32;
             dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
         } else if (seed != 0xffffu) {
-            dirtyw = c.varcons[S.varcons_off + (int)(seed - 1) * S.cw + lane];
+            dirtyw = c.itemrows[S.itemrows_off + (int)(seed - 1) * S.iw + lane];  // word (0, seed var)
         }
+    }
+    uint32_t smallmask = 0;
+    if (lane < S.iw) {
+        int left = S.nsmall - lane * 32;
+        smallmask = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
     }
     bool consistent = true;
     unsigned guard = 0;
     while (consistent) {
+        if (__ballot((dirtyw & smallmask) != 0)) {
+            // ---- lane-parallel sweep over the dirty small items
+#pragma unroll
+            for (int q = 0; q < DR; q++) {
+                int idx = q * 64 + lane;
+                if (idx < c.NK) ldom[idx] = (int)dom.r[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            bool lfail = false;
+            const int npass = (S.nsmall + 63) >> 6;
+            for (int t = 0; t < npass; t++) {
+                const int item = t * 64 + lane;
+                uint32_t dw = (uint32_t)__shfl((int)dirtyw, (item >> 5) & 63, 64);
+                const bool isd = item < S.nsmall && ((dw >> (item & 31)) & 1u);
+                unsigned long long dmask = __ballot(isd);
+                if (!dmask) continue;
+                ws.revs += (unsigned)__popcll(dmask);
+                ItemDesc it;
+                {
+                    const int *src = (const int *)&c.items[S.item_begin + (isd ? item : 0)];
+                    int *dst = (int *)&it;
+#pragma unroll
+                    for (int k = 0; k < (int)(sizeof(ItemDesc) / 4); k++) dst[k] = src[k];
+                }
+                // gathers are executed by every lane (cross-lane reads need the source lanes active)
+                uint32_t D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
+                uint32_t D2 = dom.gather(it.idx[2]), D3 = dom.gather(it.idx[3]);
+                if (isd) {
+                    if (it.type == IT_NEXT) {
+                        // X == next Y <=> X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
+                        const int sh = it.aux;
+                        uint32_t Yal = sh >= 0 ? (sh < 32 ? D1 >> sh : 0u) : (-sh < 32 ? D1 << -sh : 0u);
+                        uint32_t m = D0 & Yal;
+                        uint32_t newY = sh >= 0 ? (sh < 32 ? m << sh : 0u) : (-sh < 32 ? m >> -sh : 0u);
+                        if (m == 0) lfail = true;
+                        if (m != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], m);
+                        if (newY != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], newY);
+                    } else if (it.type == IT_UNTIL) {
+                        if (!((expire >> it.aux) & 1u) && __popc(D0) == 1 && __popc(D1) == 1) {
+                            int vx = c.var_lb[it.idx[0]] + __ffs((int)D0) - 1, vy = c.var_lb[it.idx[1]] + __ffs((int)D1) - 1;
+                            if (vx != 1 && vy != 1) lfail = true;
+                        }
+                    } else {
+                        // small extensional constraint: one row of allowed word-variable values per
+                        // tuple of the other (<= 3) variables; scan the rows of the current product
+                        if (it.arity < 2) D1 = 1u;
+                        if (it.arity < 3) D2 = 1u;
+                        if (it.arity < 4) D3 = 1u;
+                        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                        const uint32_t *tab = c.tables + it.toff;
+                        unsigned nev = 0;
+                        for (uint32_t m3 = D3; m3; m3 &= m3 - 1) {
+                            const int b3 = __ffs((int)m3) - 1;
+                            for (uint32_t m2 = D2; m2; m2 &= m2 - 1) {
+                                const int b2 = __ffs((int)m2) - 1;
+                                const int base = it.r1 * (b2 + it.r2 * b3);
+                                for (uint32_t m1 = D1; m1; m1 &= m1 - 1) {
+                                    const int b1 = __ffs((int)m1) - 1;
+                                    const uint32_t row = tab[base + b1] & D0;
+                                    nev++;
+                                    if (row) {
+                                        s0 |= row;
+                                        s1 |= 1u << b1;
+                                        s2 |= 1u << b2;
+                                        s3 |= 1u << b3;
+                                    }
+                                }
+                            }
+                        }
+                        ws.evals += nev;
+                        if (s0 == 0) lfail = true;
+                        if (s0 != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], s0);
+                        if (it.arity > 1 && s1 != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], s1);
+                        if (it.arity > 2 && s2 != D2) atomicAnd((unsigned *)&ldom[it.idx[2]], s2);
+                        if (it.arity > 3 && s3 != D3) atomicAnd((unsigned *)&ldom[it.idx[3]], s3);
+                    }
+                }
+            }
+            dirtyw &= ~smallmask;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (__ballot(lfail)) {
+                consistent = false;
+                break;
+            }
+            // read the intersection back; every changed word re-dirties the items that read it
+#pragma unroll
+            for (int q = 0; q < DR; q++) {
+                int idx = q * 64 + lane;
+                uint32_t nd = idx < c.NK ? (uint32_t)ldom[idx] : dom.r[q];
+                if (__ballot(idx < c.NK && nd == 0)) consistent = false;
+                unsigned long long cm = __ballot(nd != dom.r[q]);
+                dom.r[q] = nd;
+                while (cm) {
+                    int l = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    if (lane < S.iw) dirtyw |= c.itemrows[S.itemrows_off + (q * 64 + l) * S.iw + lane];
+                }
+            }
+            if (++guard > (1u << 20)) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+                consistent = false;
+            }
+            continue;
+        }
         unsigned long long dm = __ballot(dirtyw != 0);
         if (!dm) break;
         int wl = __ffsll((long long)dm) - 1;
         uint32_t word = rdlane(dirtyw, wl);
         int b = __ffs((int)word) - 1;
-        int ci = wl * 32 + b;
+        int item = wl * 32 + b;
         if (lane == wl) dirtyw &= ~(1u << b);
+        const int ibase = (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
+        const int ipoint = kload(c.items, ibase + 1), icon = kload(c.items, ibase + 2);
         ConDesc C;
-        load_con(c, S.con_begin + ci, C);
-        if (C.type == CT_NEXT) {
-            // X == next Y  <=>  X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
-            int sh = kload(c.var_lb, C.x) - kload(c.var_lb, C.y);
-            for (int p = 0; p + 1 < c.K && consistent; p++) {
-                int ix = p * c.N + C.x, iy = (p + 1) * c.N + C.y;
-                uint32_t DX = dom.get(ix), DY = dom.get(iy);
-                uint32_t Yal = sh >= 0 ? (sh < 32 ? DY >> sh : 0u) : (-sh < 32 ? DY << -sh : 0u);
-                uint32_t m = DX & Yal;
-                if (m == 0) {
-                    consistent = false;
-                    break;
-                }
-                uint32_t newY = sh >= 0 ? (m << sh) : (m >> -sh);
-                if (m != DX) {
-                    dom.set(ix, m, lane);
-                    if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + C.x * S.cw + lane];
-                }
-                if (newY != DY) {
-                    dom.set(iy, newY, lane);
-                    if (lane < S.cw) dirtyw |= c.varcons[S.varcons_off + C.y * S.cw + lane];
-                }
-            }
-            ws.revs++;
-        } else if (C.type == CT_POINT) {
-            for (int p = 0; p < C.npoints && consistent; p++)
-                consistent = revise_point<DR>(c, S, C, ci, p, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
-        } else if (C.type == CT_UNTIL) {
-            if (!((expire >> C.until_ordinal) & 1u)) {
-                uint32_t DX = dom.get(C.x), DY = dom.get(C.y);
-                if (__popc(DX) == 1 && __popc(DY) == 1) {
-                    int vx = kload(c.var_lb, C.x) + __ffs((int)DX) - 1, vy = kload(c.var_lb, C.y) + __ffs((int)DY) - 1;
-                    if (vx != 1 && vy != 1) consistent = false;
-                }
-            }
-            ws.revs++;
-        }
+        load_con(c, icon, C);
+        consistent = revise_point<DR>(c, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
         if (++guard > (1u << 20)) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             consistent = false;
@@ -927,6 +1030,9 @@ struct stcsp_engine {
 
     DevBuf<int> d_var_lb, d_arr_off, d_arr_data, d_sig_vars, d_until_y, d_scope, d_code, d_firstvars, d_transvals, d_miss;
     DevBuf<uint32_t> d_var_init, d_varcons, d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack;
+    DevBuf<ItemDesc> d_items;
+    DevBuf<uint32_t> d_itemrows, d_tables;
+    DevBuf<int> d_strides;
     DevBuf<SetDesc> d_sets;
     DevBuf<ConDesc> d_cons;
     DevBuf<TransDesc> d_trans;
@@ -992,6 +1098,14 @@ struct stcsp_engine {
         HIPCHK(d_trans.upload(prog.trans));
         HIPCHK(d_transvals.upload(prog.transvals));
         HIPCHK(d_varcons.upload(prog.varcons));
+        HIPCHK(d_items.upload(prog.items));
+        HIPCHK(d_itemrows.upload(prog.itemrows));
+        HIPCHK(d_tables.upload(prog.tables));
+        HIPCHK(d_strides.upload(prog.strides));
+        ctx.items = d_items.p;
+        ctx.itemrows = d_itemrows.p;
+        ctx.tables = d_tables.p;
+        ctx.strides = d_strides.p;
         ctx.sets = d_sets.p;
         ctx.cons = d_cons.p;
         ctx.scope = d_scope.p;
@@ -1002,7 +1116,7 @@ struct stcsp_engine {
         ctx.varcons = d_varcons.p;
         ctx.nsets = (int)prog.sets.size();
         ctx.stack_slots = prog.max_stack + 2;
-        lds_bytes = (size_t)4 * (kMaxLowVars + ctx.stack_slots) * 64 * sizeof(int);
+        lds_bytes = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 63) & ~63)) * sizeof(int);
         if (lds_bytes > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         return STCSP_OK;
     }
