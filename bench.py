@@ -107,13 +107,17 @@ def main():
         one_step()
     barrier()
     t0 = time.perf_counter()
-    nodes = leaves = 0
+    nodes = leaves = revs = evals = wrevs = sweeps = 0
     k_time = 0.0
     k_launches = 0
     for _ in range(args.steps):
         c = one_step()
         nodes += c.search_nodes
         leaves += c.leaves
+        revs += c.revisions
+        evals += c.evaluations
+        wrevs += c.wave_revisions
+        sweeps += c.sweeps
         k_time += c.seconds_expand_kernel
         k_launches += c.expand_launches
     barrier()
@@ -165,7 +169,10 @@ def main():
             "config": {"workload": f"{args.workload}.csp (generated by stcsp-solver_amd/instances.py; "
                                    f"{N} vars incl. aux, prefix K={K}, whole frontier resident in HBM)",
                        "nodes_per_step": nodes // args.steps, "leaves_per_step": leaves // args.steps,
-                       "launch_rounds_per_step": int(levels), "sharding": "none" if world == 1 else f"state-owner x{world}"},
+                       "launch_rounds_per_step": int(levels),
+                       "per_node": {"item_revisions": revs / max(nodes, 1), "tuple_evaluations": evals / max(nodes, 1),
+                                    "wavefront_revisions": wrevs / max(nodes, 1), "sweeps": sweeps / max(nodes, 1)},
+                       "sharding": "none" if world == 1 else f"state-owner x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_expand",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,

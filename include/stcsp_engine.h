@@ -127,6 +127,8 @@ typedef struct stcsp_counters {
        over its launches, on the stream it is launched on */
     double seconds_expand_kernel;
     int64_t expand_launches;
+    int64_t wave_revisions; /* engine only: revisions done by a whole wavefront (bitmap / bytecode) */
+    int64_t sweeps;         /* engine only: lane-per-item sweeps over the small constraints         */
 } stcsp_counters;
 
 /* The automaton as the search leaves it in solver->graph, before graphTraverse.

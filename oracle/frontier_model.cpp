@@ -301,7 +301,7 @@ struct Model {
         uint32_t new_expire = expire;
         for (int j = 0; j < mgr.n_sig; j++) {
             int v = mgr.sig_vars[j];
-            rec[4 + j] = (uint32_t)(mgr.lb[v] + __builtin_ctz(blk[v]));
+            rec[kCandHdr + j] = (uint32_t)(mgr.lb[v] + __builtin_ctz(blk[v]));
         }
         for (int u = 0; u < mgr.n_until_cons; u++) {
             int y = mgr.until_y[u];
@@ -310,17 +310,20 @@ struct Model {
                 ex = true;
                 new_expire |= 1u << u;
             }
-            rec[4 + mgr.n_sig + u] = ex;
+            rec[kCandHdr + mgr.n_sig + u] = ex;
         }
         rec[3] = new_expire;
-        uint32_t *vals = rec.data() + 4 + sig_len, *nb = vals + N;
+        uint32_t *vals = rec.data() + kCandHdr + sig_len, *nb = vals + N;
         for (int v = 0; v < N; v++) vals[v] = (uint32_t)(mgr.lb[v] + __builtin_ctz(blk[v]));
         for (int p = 0; p < K; p++)
             for (int v = 0; v < N; v++) nb[p * N + v] = (p + 1 < K) ? blk[(p + 1) * N + v] : init[v];
         std::vector<uint32_t> kw(KL);
         kw[0] = rec[2];
-        for (int j = 0; j < sig_len; j++) kw[1 + j] = rec[4 + j];
-        int owner = (int)((key_hash(kw.data()) >> 40) % (unsigned)opt.world);
+        for (int j = 0; j < sig_len; j++) kw[1 + j] = rec[kCandHdr + j];
+        unsigned long long hh = key_hash(kw.data());
+        rec[4] = (uint32_t)hh;
+        rec[5] = (uint32_t)(hh >> 32);
+        int owner = (int)((hh >> 40) % (unsigned)opt.world);
         outbox[owner].insert(outbox[owner].end(), rec.begin(), rec.end());
         return STCSP_OK;
     }
@@ -330,7 +333,7 @@ struct Model {
             const uint32_t *rec = recs + (size_t)i * CS;
             std::vector<uint32_t> kw(KL);
             kw[0] = rec[2];
-            for (int j = 0; j < sig_len; j++) kw[1 + j] = rec[4 + j];
+            for (int j = 0; j < sig_len; j++) kw[1 + j] = rec[kCandHdr + j];
             auto it = table.find(kw);
             uint32_t idx;
             bool is_new = false;
@@ -344,7 +347,7 @@ struct Model {
             }
             e_src.push_back((int64_t)(((uint64_t)rec[1] << 32) | rec[0]));
             e_dst.push_back(((int64_t)opt.rank << STCSP_GID_SHIFT) | idx);
-            const uint32_t *vals = rec + 4 + sig_len;
+            const uint32_t *vals = rec + kCandHdr + sig_len;
             for (int v = 0; v < N; v++) e_val.push_back((int32_t)vals[v]);
             if (is_new) {
                 int set = mgr.find_tag((int32_t)rec[2]);

@@ -20,6 +20,7 @@ constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revis
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
+constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
 constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap compiled per constraint
 
@@ -130,9 +131,9 @@ constexpr unsigned long long kHashSeed = 0x9E3779B97F4A7C15ull;
 
 // record strides in words (all multiples of 4)
 STCSP_HD int node_stride(int N, int K) { return (4 + N * K + 3) & ~3; }
-STCSP_HD int cand_stride(int N, int K, int sig_len) { return (4 + sig_len + N + N * K + 3) & ~3; }
+STCSP_HD int cand_stride(int N, int K, int sig_len) { return (kCandHdr + sig_len + N + N * K + 3) & ~3; }
 STCSP_HD int edge_stride(int N) { return (4 + N + 3) & ~3; }
-// candidate record: [0,1] src gid  [2] next set tag  [3] expire bits  [4..) signature,
-//                   then N edge-label values, then the N*K time-advanced block
+// candidate record: [0,1] src gid  [2] next set tag  [3] expire bits  [4,5] key hash  [6,7] spare
+//                   [8..) signature, then N edge-label values, then the N*K time-advanced block
 
 }  // namespace stcsp

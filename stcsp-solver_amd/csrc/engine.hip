@@ -53,8 +53,8 @@ namespace {
 constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
-constexpr int kStatWords = 8;
-enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_SPARE };
+constexpr int kStatWords = 16;
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS };
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
@@ -172,7 +172,7 @@ struct Dom {
 };
 
 struct WaveStats {
-    unsigned revs = 0;
+    unsigned revs = 0, wave_revs = 0, sweeps = 0;
     unsigned long long evals = 0;
 };
 
@@ -366,6 +366,7 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
         }
     }
     ws.revs++;
+    ws.wave_revs++;
     const unsigned nact = (unsigned)min(P, 64);
     // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
     // value of every high variable appears once, so loose constraints finish here.
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             bool lfail = false;
+            ws.sweeps++;
             const int npass = (S.nsmall + 63) >> 6;
             for (int t = 0; t < npass; t++) {
                 const int item = t * 64 + lane;
@@ -680,6 +682,8 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         add_stats(c, gw, ST_NODES, 1);
         add_stats(c, gw, ST_REVS, ws.revs);
         add_stats(c, gw, ST_EVALS, ws.evals);
+        add_stats(c, gw, ST_WAVEREVS, ws.wave_revs);
+        add_stats(c, gw, ST_SWEEPS, ws.sweeps);
     }
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
@@ -795,9 +799,10 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         return;
     }
     uint32_t *rec = a.cand_base + ((size_t)(owner * R + ro) * a.cand_cap + pos) * c.CS;
-    if (lane < 4) rec[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? next_tag : new_expire));
-    if (lane >= 1 && lane <= c.sig_len) rec[4 + lane - 1] = kw;
-    uint32_t *vals = rec + 4 + c.sig_len;
+    if (lane < 6)
+        rec[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? next_tag : (lane == 3 ? new_expire : (lane == 4 ? (uint32_t)h : (uint32_t)(h >> 32)))));
+    if (lane >= 1 && lane <= c.sig_len) rec[kCandHdr + lane - 1] = kw;
+    uint32_t *vals = rec + kCandHdr + c.sig_len;
     uint32_t *blk = vals + c.N;
 #pragma unroll
     for (int q = 0; q < DR; q++) {
@@ -836,13 +841,12 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
         if (gw >= a.total) return;
         rec = a.cand_base + (size_t)gw * c.CS;
     }
-    const uint32_t s0 = rflu(rec[0]), s1 = rflu(rec[1]), tag = rflu(rec[2]), expire = rflu(rec[3]);
+    uint32_t hw = lane < 6 ? rec[lane] : 0u;  // one coalesced header read
+    const uint32_t s0 = rdlane(hw, 0), s1 = rdlane(hw, 1), tag = rdlane(hw, 2), expire = rdlane(hw, 3);
+    const unsigned long long h = ((unsigned long long)rdlane(hw, 5) << 32) | rdlane(hw, 4);  // computed by k_expand
     uint32_t kw = 0;
     if (lane == 0) kw = tag;
-    if (lane >= 1 && lane <= c.sig_len) kw = rec[4 + lane - 1];
-    unsigned long long h = kHashSeed;
-    for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
-    h = mix_final(h);
+    if (lane >= 1 && lane <= c.sig_len) kw = rec[kCandHdr + lane - 1];
     const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
     uint32_t pos = (uint32_t)h & c.slot_mask;
 
@@ -892,7 +896,8 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
                     return;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // no acquire fence: every access to a key word is an agent-scope (sc1, L1-bypassing)
+            // atomic, the publisher drained its stores before the index became visible
             uint32_t other = 0;
             if (lane < c.KL) other = __hip_atomic_load(&c.state_keys[(size_t)lo * c.KL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__ballot(lane < c.KL && other != kw)) {
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     }
     uint32_t *er = c.edges + ((size_t)ro * c.edge_cap + e) * c.ES;
     if (lane < 4) er[lane] = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? idx : 0u));
-    const uint32_t *vals = rec + 4 + c.sig_len;
+    const uint32_t *vals = rec + kCandHdr + c.sig_len;
     for (int v = lane; v < c.N; v += 64) er[4 + v] = vals[v];
     if (!is_new) return;
     // new state: open its first search node (the successor block travelled with the candidate)
@@ -1493,6 +1498,8 @@ struct stcsp_engine {
         ctr.leaves = (int64_t)tot[ST_LEAVES];
         ctr.revisions = (int64_t)tot[ST_REVS];
         ctr.evaluations = (int64_t)tot[ST_EVALS];
+        ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
+        ctr.sweeps = (int64_t)tot[ST_SWEEPS];
         ctr.levels = levels;
         ctr.seconds_search = finished ? seconds_search : elapsed();
         ctr.seconds_expand_kernel = seconds_expand_kernel;
