@@ -1,0 +1,56 @@
+"""Worker for the multi-process tests of the sharded driver (one process per shard)."""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+
+
+def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
+    import torch
+    import torch.distributed as dist
+
+    st = importlib.import_module("stcsp-solver_amd")
+    sh = importlib.import_module("stcsp-solver_amd.sharded")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = st.Model.from_name(name, prefix_k=prefix_k)
+    if backend_kind == "fmodel":
+        # CPU stand-in for the HIP engine (tests only): oracle/frontier_model.cpp
+        lib = C.CDLL(str(REPO / "oracle" / "libstcsp_oracle.so"))
+        st.bind_engine_api(lib, "stcsp_fmodel")
+
+        class FModel(st.EngineBase):
+            _prefix = "stcsp_fmodel"
+
+            def __init__(self, model, **o):
+                super().__init__(lib, model, **o)
+
+        eng = FModel(m, rank=rank, world=world)
+        device = torch.device("cpu")
+        rounds = sh.solve_sharded(eng, rank, world, device)
+    else:
+        # the real HIP engine, every shard on GPU 0, all-to-all staged through host (gloo)
+        eng = st.Engine(m, device=0, rank=rank, world=world)
+        device = torch.device("cuda:0")
+        rounds = sh.solve_sharded(eng, rank, world, device, stage_through_host=True)
+    merged = sh.gather_and_merge(st, eng, rank, world)
+    if rank == 0:
+        h, res = merged
+        a = st.Automaton(m, res).traverse().renumber()
+        out = dict(states=a.n_live_states, edges=a.n_live_edges, sha=a.canonical_sha256(), rounds=rounds,
+                   table=res.n_states, dom=res.counters.dominance, nodes=res.counters.search_nodes,
+                   sets=res.n_constraint_sets)
+        Path(out_path).write_text(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    rank, world, port, name, kind, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+    run(rank, world, port, name, kind, out)

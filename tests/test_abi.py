@@ -1,0 +1,49 @@
+"""The C-ABI libraries load and export every symbol the headers declare (no compute calls)."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def declared(header):
+    text = (REPO / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(stcsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_engine_library_exports_every_declared_symbol(stcsp):
+    subprocess.run(["make", "-C", str(stcsp.CSRC), "libstcsp_hip.so"], check=True, capture_output=True)
+    lib = C.CDLL(str(stcsp.CSRC / "libstcsp_hip.so"))  # links libamdhip64: loads without a GPU
+    names = declared("stcsp_engine.h")
+    assert set(names) == set(stcsp.ENGINE_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_library_exports_every_declared_symbol(stcsp):
+    lib = stcsp.host_lib()
+    names = declared("stcsp_host.h")
+    assert set(names) == set(stcsp.HOST_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_engine_fails_loudly_without_gpu(stcsp):
+    """No CPU fallback: on a machine without a GPU, creating an engine is an error."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    m = stcsp.Model.from_name("juggling_b4_f4")
+    with pytest.raises(stcsp.StcspError) as e:
+        stcsp.Engine(m)
+    assert e.value.code == -3  # STCSP_E_DEVICE
+
+
+def test_abi_struct_sizes(stcsp):
+    # mirrors of include/stcsp_engine.h (LP64)
+    assert C.sizeof(stcsp.Node) == 24
+    assert C.sizeof(stcsp.Options) == 40
+    assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 16

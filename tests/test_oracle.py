@@ -1,0 +1,114 @@
+"""The oracle is pinned before it is trusted: oracle/ref_dfs.cpp must reproduce the reference's
+recorded outputs -- canonical sha256 of the automaton AND the reference's own counters (stats
+line dom/node/fail, search nodes, arc revisions, validate calls) -- and oracle/frontier_model.cpp
+(the scalar model of the build's algorithm, running the product's compiled constraint program)
+must agree with it on the automaton."""
+import hashlib
+import json
+import os
+from pathlib import Path
+
+import pytest
+
+from conftest import finish
+from canon import canon_sha256
+
+REPO = Path(__file__).resolve().parents[1]
+PROBES = json.loads((REPO / "tests" / "golden" / "reference_probes.json").read_text())
+
+FAST = ["juggling_b4_f4", "juggling_b4_f5", "juggling_b4_f6", "juggling_b5_f5", "juggling_b6_f6",
+        "juggling_b4_f4_nosym", "juggling_b4_f5_nosym", "juggling_b5_f5_nosym", "juggling_b4_f6_nosym",
+        "digitinvader1", "digitinvader2", "digitinvader3", "digitinvader4", "partialorder_10", "partialorder_11"]
+SLOW = ["juggling_b5_f6", "juggling_b5_f6_nosym", "juggling_b6_f6_nosym", "digitinvader5", "digitinvader6",
+        "digitinvader7", "digitinvader8", "digitinvader9", "partialorder_12", "partialorder_13", "partialorder_14"]
+slow = pytest.mark.skipif(not os.environ.get("STCSP_SLOW"), reason="minutes of CPU; set STCSP_SLOW=1")
+
+
+def check_ref(stcsp, RefOracle, golden, name, tmp_path):
+    m = stcsp.Model.from_name(name)
+    o = RefOracle(m)
+    r = o.solve()
+    a, _ = finish(o, r)
+    g, c = golden[name], r.counters
+    got = dict(var=m.n_vars, con=m.n_constraints, dom=c.dominance, node=r.n_states, fail=c.fails,
+               search=c.search_nodes, revisions=c.revisions, validate=c.evaluations,
+               states=a.n_live_states, edges=a.n_live_edges, canonical_sha256=a.canonical_sha256())
+    assert got == g
+    # the dot writer + the survey's normative canonicaliser give the same hash as the C++ one
+    dot = tmp_path / "solutions.dot"
+    a.write_dot(str(dot))
+    sha, ns, ne = canon_sha256(str(dot))
+    assert (sha, ns, ne) == (g["canonical_sha256"], g["states"], g["edges"])
+    assert dot.read_text().splitlines()[0] == f"# Number of nodes = {g['node']}"
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_ref_oracle_reproduces_reference(stcsp, RefOracle, golden, name, tmp_path):
+    check_ref(stcsp, RefOracle, golden, name, tmp_path)
+
+
+@slow
+@pytest.mark.parametrize("name", SLOW)
+def test_ref_oracle_reproduces_reference_slow(stcsp, RefOracle, golden, name, tmp_path):
+    check_ref(stcsp, RefOracle, golden, name, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["juggling_b4_f4", "juggling_b4_f5", "juggling_b5_f5", "juggling_b4_f4_nosym",
+                                  "juggling_b4_f5_nosym", "digitinvader1", "digitinvader2", "digitinvader3"])
+def test_frontier_model_matches_reference(stcsp, FrontierModel, golden, name):
+    m = stcsp.Model.from_name(name)
+    f = FrontierModel(m)
+    r = f.solve()
+    a, _ = finish(f, r)
+    g = golden[name]
+    assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (g["states"], g["edges"], g["canonical_sha256"])
+    assert r.counters.dominance == g["dom"]
+
+
+@pytest.mark.parametrize("probe", ["until", "arr", "at", "misc", "adversarial"])
+def test_feature_probes(stcsp, RefOracle, FrontierModel, probe):
+    """until / arr / @ / abs,not,-> / adversarial: reference stats line + recorded dot facts."""
+    p = PROBES[probe]
+    m = stcsp.Model(text=p["text"])
+    o = RefOracle(m)
+    r = o.solve()
+    assert [m.n_vars, m.n_constraints, r.counters.dominance, r.n_states, r.counters.fails] == p["stats"]
+    a, _ = finish(o, r)
+    if "live_states" in p:
+        assert a.n_live_states == p["live_states"]
+    if "live_edges" in p:
+        assert a.n_live_edges == p["live_edges"]
+    if "root_final" in p:
+        assert a.canonical().splitlines()[2].split()[3] == str(p["root_final"])
+    if "constraint_sets" in p:
+        assert r.n_constraint_sets == p["constraint_sets"]
+    if "edge_labels" in p:
+        labels = {tuple(int(x) for x in ln.split()[3:]) for ln in a.canonical().splitlines() if ln.startswith("E ")}
+        assert labels == {tuple(l) for l in p["edge_labels"]}
+    # the frontier model agrees on the automaton
+    f = FrontierModel(m)
+    af, _ = finish(f, f.solve())
+    assert af.canonical() == a.canonical()
+    if probe == "adversarial":
+        o1 = RefOracle(m)
+        a1, adv = finish(o1, o1.solve(), adversarial="a")
+        assert adv == p["adver1"] and (a1.n_live_states, a1.n_live_edges) == (p["adver1_live_states"], p["adver1_live_edges"])
+        o2 = RefOracle(m)
+        a2, adv2 = finish(o2, o2.solve(), adversarial="z")
+        assert adv2 == p["adver2"] and a2.canonical().endswith("EMPTY\n")
+
+
+def test_prefix_k3_gives_same_automaton(stcsp, RefOracle, FrontierModel, golden):
+    """Look-ahead strength does not change the automaton (K=2 and K=3 agree)."""
+    m = stcsp.Model.from_name("juggling_b4_f5", prefix_k=3)
+    for cls in (RefOracle, FrontierModel):
+        e = cls(m)
+        a, _ = finish(e, e.solve())
+        assert a.canonical_sha256() == golden["juggling_b4_f5"]["canonical_sha256"]
+
+
+def test_oracle_time_box(stcsp, RefOracle):
+    m = stcsp.Model.from_name("partialorder_12")
+    o = RefOracle(m, max_search_nodes=5000)
+    r = o.solve()
+    assert r.truncated == 1 and 5000 <= r.counters.search_nodes <= 5100
