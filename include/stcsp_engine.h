@@ -129,6 +129,8 @@ typedef struct stcsp_counters {
     int64_t expand_launches;
     int64_t wave_revisions; /* engine only: revisions done by a whole wavefront (bitmap / bytecode) */
     int64_t sweeps;         /* engine only: lane-per-item sweeps over the small constraints         */
+    int64_t skipped_revisions; /* engine only: revisions skipped because the product to refute
+                                  exceeded the per-revision budget (sound, see engine.hip)          */
 } stcsp_counters;
 
 /* The automaton as the search leaves it in solver->graph, before graphTraverse.

@@ -54,7 +54,7 @@ constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
 constexpr int kStatWords = 16;
-enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS };
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED };
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
@@ -172,7 +172,7 @@ struct Dom {
 };
 
 struct WaveStats {
-    unsigned revs = 0, wave_revs = 0, sweeps = 0;
+    unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
     unsigned long long evals = 0;
 };
 
@@ -363,6 +363,28 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
             hm &= hm - 1;
             int nj = (int)rdlane((uint32_t)n, j);
             if (nj > maxn) maxn = nj;
+        }
+    }
+    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the
+    // wave-uniform part of that product (the odometer range) is larger than the budget the
+    // revision could never finish, so it is skipped outright. This keeps propagation sound (no
+    // value is ever removed without proof) and the search complete: at a leaf every variable is a
+    // singleton, the product is 1 and the constraint is checked exactly -- the same argument that
+    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield
+    // the same automaton.
+    {
+        const unsigned long long budget = use_bitmap ? kBudgetBitmapIters : kBudgetCodeIters;
+        unsigned long long total_hi = 1;
+        unsigned long long hm = highmask;
+        while (hm && total_hi <= budget) {
+            int j = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            total_hi *= (unsigned long long)rdlane((uint32_t)n, j);
+        }
+        if (total_hi > budget) {
+            if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+            ws.skipped++;
+            return true;
         }
     }
     ws.revs++;
@@ -684,6 +706,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         add_stats(c, gw, ST_EVALS, ws.evals);
         add_stats(c, gw, ST_WAVEREVS, ws.wave_revs);
         add_stats(c, gw, ST_SWEEPS, ws.sweeps);
+        add_stats(c, gw, ST_SKIPPED, ws.skipped);
     }
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
@@ -1500,6 +1523,7 @@ struct stcsp_engine {
         ctr.evaluations = (int64_t)tot[ST_EVALS];
         ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
         ctr.sweeps = (int64_t)tot[ST_SWEEPS];
+        ctr.skipped_revisions = (int64_t)tot[ST_SKIPPED];
         ctr.levels = levels;
         ctr.seconds_search = finished ? seconds_search : elapsed();
         ctr.seconds_expand_kernel = seconds_expand_kernel;

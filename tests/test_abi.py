@@ -46,4 +46,4 @@ def test_abi_struct_sizes(stcsp):
     # mirrors of include/stcsp_engine.h (LP64)
     assert C.sizeof(stcsp.Node) == 24
     assert C.sizeof(stcsp.Options) == 40
-    assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 16
+    assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 24

@@ -8,13 +8,18 @@ from conftest import finish
 
 pytestmark = pytest.mark.gpu
 
-SMALL = ["juggling_b4_f4", "juggling_b4_f5", "juggling_b4_f4_nosym", "juggling_b5_f5", "digitinvader1",
-         "digitinvader2", "juggling_b4_f5_nosym", "juggling_b4_f6", "digitinvader3", "partialorder_10"]
-MEDIUM = ["juggling_b5_f5_nosym", "juggling_b4_f6_nosym", "juggling_b6_f6", "digitinvader4", "partialorder_11",
-          "partialorder_12"]
+import json
+from pathlib import Path
+
+PROBES = json.loads((Path(__file__).resolve().parent / "golden" / "reference_probes.json").read_text())
 
 
-@pytest.mark.parametrize("name", SMALL + MEDIUM)
+def all_examples():
+    import importlib
+    return importlib.import_module("stcsp-solver_amd").instances.REFERENCE_EXAMPLES
+
+
+@pytest.mark.parametrize("name", all_examples())
 def test_engine_matches_reference_golden(stcsp, golden, name):
     """Canonical automaton (states keyed by (set, signature), final flags, labelled edges)
     bit-identical to the reference's: sha256 of the canonical text equals the recorded value."""
@@ -27,8 +32,75 @@ def test_engine_matches_reference_golden(stcsp, golden, name):
     assert a.n_live_edges == g["edges"]
     assert a.canonical_sha256() == g["canonical_sha256"]
     assert r.counters.dominance == g["dom"]          # order-independent
+    assert r.truncated == 0
     if g["fail"] == 0:
+        # table size (failed look-ahead states included) and the search tree itself coincide with
+        # the reference's whenever the reference never fails
         assert r.n_states == g["node"]
+        assert r.counters.search_nodes == g["search"]
+
+
+@pytest.mark.parametrize("probe", ["until", "arr", "at", "misc", "adversarial"])
+def test_engine_feature_probes(stcsp, RefOracle, probe):
+    """until / arr (+ out-of-range `valid`) / @ (4 constraint sets) / abs,not,-> / adversarial:
+    the reference's stats line columns and the oracle's canonical automaton."""
+    p = PROBES[probe]
+    m = stcsp.Model(text=p["text"])
+    e = stcsp.Engine(m)
+    r = e.solve()
+    assert [m.n_vars, m.n_constraints, r.counters.dominance, r.n_states, r.counters.fails] == p["stats"]
+    a, _ = finish(e, r)
+    o = RefOracle(m)
+    ao, _ = finish(o, o.solve())
+    assert a.canonical() == ao.canonical()
+    if "constraint_sets" in p:
+        assert r.n_constraint_sets == p["constraint_sets"]
+    if probe == "adversarial":
+        e1 = stcsp.Engine(m)
+        a1, adv = finish(e1, e1.solve(), adversarial="a")
+        assert adv == p["adver1"] and (a1.n_live_states, a1.n_live_edges) == (p["adver1_live_states"], p["adver1_live_edges"])
+        e2 = stcsp.Engine(m)
+        a2, adv2 = finish(e2, e2.solve(), adversarial="z")
+        assert adv2 == p["adver2"] and a2.canonical().endswith("EMPTY\n")
+
+
+def test_engine_resolve_and_limits(stcsp, golden):
+    """solve() may be called repeatedly (the reference's -t loop re-solves the model); node and
+    time limits truncate cleanly."""
+    m = stcsp.Model.from_name("partialorder_10")
+    e = stcsp.Engine(m)
+    for _ in range(3):
+        a, _ = finish(e, e.solve())
+        assert a.canonical_sha256() == golden["partialorder_10"]["canonical_sha256"]
+    e2 = stcsp.Engine(m, max_search_nodes=2000, batch_nodes=256)
+    r = e2.solve()
+    assert r.truncated == 1 and r.counters.search_nodes >= 2000
+
+
+def test_engine_small_batches_depth_first(stcsp, golden):
+    """A tiny launch batch forces the chunked, depth-first segment stack (bounded frontier
+    memory) instead of level-synchronous expansion: same automaton."""
+    for name in ["juggling_b4_f5_nosym", "digitinvader3", "partialorder_10"]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m, batch_nodes=64)
+        a, _ = finish(e, e.solve())
+        assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
+
+
+def test_engine_prefix_k3(stcsp, golden):
+    m = stcsp.Model.from_name("juggling_b4_f5", prefix_k=3)
+    e = stcsp.Engine(m)
+    a, _ = finish(e, e.solve())
+    assert a.canonical_sha256() == golden["juggling_b4_f5"]["canonical_sha256"]
+
+
+def test_engine_rejects_wide_domains(stcsp):
+    """Aux variables of / and % get [INT_MIN, INT_MAX] (solveralgorithm.cpp:316-322): outside the
+    bitset path -> a clean STCSP_E_UNSUPPORTED, never a crash."""
+    m = stcsp.Model(text="var x:[0,3]; var y:[1,3]; next x == x / y;")
+    with pytest.raises(stcsp.StcspError) as ex:
+        stcsp.Engine(m)
+    assert ex.value.code == -2
 
 
 @pytest.mark.parametrize("name", ["juggling_b4_f5", "digitinvader2", "juggling_b4_f4_nosym"])
