@@ -97,7 +97,7 @@ def test_engine_prefix_k3(stcsp, golden):
 def test_engine_rejects_wide_domains(stcsp):
     """Aux variables of / and % get [INT_MIN, INT_MAX] (solveralgorithm.cpp:316-322): outside the
     bitset path -> a clean STCSP_E_UNSUPPORTED, never a crash."""
-    m = stcsp.Model(text="var x:[0,3]; var y:[1,3]; next x == x / y;")
+    m = stcsp.Model(text="var x:[0,3]; var y:[1,3]; var z:[0,3]; z == next (x / y);")
     with pytest.raises(stcsp.StcspError) as ex:
         stcsp.Engine(m)
     assert ex.value.code == -2
