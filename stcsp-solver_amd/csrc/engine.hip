@@ -36,6 +36,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -73,26 +74,20 @@ enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
 enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
        ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
 
+struct ImgOff {
+    int sets, cons, scope, strides, items, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
+        arr_off, words;
+};
+
 struct Ctx {
     int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
-    const int *var_lb;
-    const uint32_t *var_init;
-    const int *arr_off;
-    const int *arr_data;
-    const int *sig_vars;
-    const int *until_y;
-    const SetDesc *sets;
-    const ConDesc *cons;
-    const int *scope;
+    // the compiled program: one contiguous image of 32-bit words (sections at the offsets in `o`),
+    // staged into LDS by every workgroup of k_expand when it fits; the bytecode and the
+    // user arrays (potentially large) stay in global memory
+    const uint32_t *img;
+    ImgOff o;
     const int *code;
-    const int *firstvars;
-    const TransDesc *trans;
-    const int *transvals;
-    const uint32_t *varcons;
-    const ItemDesc *items;
-    const uint32_t *itemrows;
-    const uint32_t *tables;
-    const int *strides;
+    const int *arr_data;
     unsigned long long *slots;
     uint32_t slot_mask;
     uint32_t *state_keys;
@@ -127,6 +122,14 @@ struct CommitArgs {
 };
 
 // ------------------------------------------------------------------ device helpers
+// View of the program image: L = true -> the workgroup's LDS copy, false -> global memory.
+// u(): wave-uniform read (scalar load / broadcast LDS read), v(): per-lane read.
+template <bool L>
+struct Img {
+    const uint32_t *p;
+    __device__ __forceinline__ int v(int off) const { return (int)p[off]; }
+    __device__ __forceinline__ int u(int off) const;
+};
 // The compiled program (bytecode, descriptors, tables) is read-only for the lifetime of a launch
 // and indexed wave-uniformly: reading it through the constant address space makes hipcc emit
 // scalar loads (s_load_dword through the scalar cache) instead of 64-lane vector loads.
@@ -134,6 +137,10 @@ typedef const __attribute__((address_space(4))) int *kptr;
 __device__ __forceinline__ int kload(const void *base, int idx) {
     return ((kptr)(const __attribute__((address_space(1))) int *)base)[idx];
 }
+template <>
+__device__ __forceinline__ int Img<true>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)p[off]); }
+template <>
+__device__ __forceinline__ int Img<false>::u(int off) const { return kload(p, off); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -180,7 +187,8 @@ struct WaveStats {
 // reference src/solveralgorithm.cpp:336-424). varinfo/curval are per-lane registers indexed by
 // scope position: varinfo = 1 + slot for lane-enumerated variables (value in lds_vals), 0 for
 // wave-uniform ones (value in curval).
-__device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uint32_t varinfo, int curval,
+template <bool L>
+__device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_valid, int lane, uint32_t varinfo, int curval,
                             const int *lds_vals, int *lds_stk) {
     int t = 0, sp = 0;
     bool valid = true;
@@ -206,7 +214,7 @@ __device__ int eval_program(const Ctx &c, int pc, bool uses_valid, int lane, uin
                 break;
             }
             case OP_ARR: {
-                int off = kload(c.arr_off, arg), size = kload(c.arr_off, arg + 1) - off;
+                int off = P.u(c.o.arr_off + arg), size = P.u(c.o.arr_off + arg + 1) - off;
                 bool inr = (unsigned)t < (unsigned)size;
                 if (!inr && dead == 0) valid = false;
                 t = inr ? c.arr_data[off + t] : 0;
@@ -276,23 +284,23 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-template <int DR>
-__device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom, int lane,
-                             uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
+template <int DR, bool L>
+__device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
     uint32_t D = 0;
     if (lane < s) {
-        var = c.scope[C.scope_off + lane];
+        var = G.v(c.o.scope + C.scope_off + lane);
         }
     D = dom.gather(p * c.N + var);
     if (lane >= s) D = 0;
     int n = lane < s ? __popc(D) : 1;
     if (__ballot(lane < s && n == 0)) return false;
-    int vlb = lane < s ? c.var_lb[var] : 0;
+    int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
     const bool use_bitmap = C.bitmap_off >= 0;
-    const int mystride = (use_bitmap && lane < s) ? c.strides[C.stride_off + lane] : 0;
+    const int mystride = (use_bitmap && lane < s) ? G.v(c.o.strides + C.stride_off + lane) : 0;
     int lane_part = 0;  // bitmap: this lane's tuple index contribution of the lane-enumerated variables
 
     // --- split the scope: up to kMaxLowVars variables whose domain sizes multiply to <= 64 are
@@ -416,9 +424,9 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
         int res;
         if (use_bitmap) {
             int bit = lane_part + wave_sum(is_uniform ? curbit * mystride : 0);
-            res = active ? (int)((c.tables[C.bitmap_off + (bit >> 5)] >> (bit & 31)) & 1u) : 0;
+            res = active ? (int)(((uint32_t)G.v(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
         } else {
-            res = eval_program(c, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
         }
         ws.evals += nact;
         unsigned long long sm = __ballot(active && res != 0);
@@ -479,7 +487,7 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
         if (newD != Dj) {
             int vj = (int)rdlane((uint32_t)var, j);
             dom.set(p * c.N + vj, newD, lane);
-            if (lane < S.iw) dirtyw |= c.itemrows[S.itemrows_off + (p * c.N + vj) * S.iw + lane];
+            if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
         }
     }
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
@@ -488,15 +496,17 @@ __device__ bool revise_point(const Ctx &c, const SetDesc &S, const ConDesc &C, i
     return ok;
 }
 
-__device__ __forceinline__ void load_set(const Ctx &c, int set, SetDesc &S) {
+template <bool L>
+__device__ __forceinline__ void load_set(const Ctx &c, const Img<L> &P, int set, SetDesc &S) {
     int *dst = (int *)&S;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = kload(c.sets, set * (int)(sizeof(SetDesc) / 4) + i);
+    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = P.u(c.o.sets + set * (int)(sizeof(SetDesc) / 4) + i);
 }
-__device__ __forceinline__ void load_con(const Ctx &c, int idx, ConDesc &C) {
+template <bool L>
+__device__ __forceinline__ void load_con(const Ctx &c, const Img<L> &P, int idx, ConDesc &C) {
     int *dst = (int *)&C;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = kload(c.cons, idx * (int)(sizeof(ConDesc) / 4) + i);
+    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = P.u(c.o.cons + idx * (int)(sizeof(ConDesc) / 4) + i);
 }
 
 __device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
@@ -515,22 +525,17 @@ __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t
 }
 
 // ------------------------------------------------------------------ k_expand
-template <int DR>
-__global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + wib;
+// expand ONE open node (slot `gw` of this launch) with one wavefront
+template <int DR, bool L>
+__device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
     const int r = gw % R, i = gw / R;
     if (i >= a.take[r]) return;
     // outputs go to another cursor shard than the input's, or a subtree would stay in the region
     // of its root forever; for every i exactly one input region maps to each output region, so
     // an output region receives from at most max(take) wavefronts
     const int ro = (i + r) % R;
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
-    int *lds_vals = smem + wib * per_wave;
-    int *lds_stk = lds_vals + kMaxLowVars * 64;
-    const CtlLayout L(c.world);
-    uint32_t *misc = c.ctl + L.misc0;
+    const CtlLayout L_(c.world);
+    uint32_t *misc = c.ctl + L_.misc0;
 
     const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(a.count[r] - 1 - i)) * c.NS;
     Dom<DR> dom;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     const uint32_t seed = w2 >> 16;
     const uint32_t expire = rflu(node[3]);
     SetDesc S;
-    load_set(c, set, S);
+    load_set<L>(c, P, set, S);
 
     // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). Work items
     // are (constraint, time point) pairs; the dirty mask is lane-striped (lane w holds word w).
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
             int left = S.nitems - lane * 32;
             dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
         } else if (seed != 0xffffu) {
-            dirtyw = c.itemrows[S.itemrows_off + (int)(seed - 1) * S.iw + lane];  // word (0, seed var)
+            dirtyw = (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (int)(seed - 1) * S.iw + lane);  // word (0, seed var)
         }
     }
     uint32_t smallmask = 0;
@@ -597,10 +602,10 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                 ws.revs += (unsigned)__popcll(dmask);
                 ItemDesc it;
                 {
-                    const int *src = (const int *)&c.items[S.item_begin + (isd ? item : 0)];
+                    const int ioff = c.o.items + (S.item_begin + (isd ? item : 0)) * (int)(sizeof(ItemDesc) / 4);
                     int *dst = (int *)&it;
 #pragma unroll
-                    for (int k = 0; k < (int)(sizeof(ItemDesc) / 4); k++) dst[k] = src[k];
+                    for (int k = 0; k < (int)(sizeof(ItemDesc) / 4); k++) dst[k] = P.v(ioff + k);
                 }
                 // gathers are executed by every lane (cross-lane reads need the source lanes active)
                 uint32_t D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                         if (newY != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], newY);
                     } else if (it.type == IT_UNTIL) {
                         if (!((expire >> it.aux) & 1u) && __popc(D0) == 1 && __popc(D1) == 1) {
-                            int vx = c.var_lb[it.idx[0]] + __ffs((int)D0) - 1, vy = c.var_lb[it.idx[1]] + __ffs((int)D1) - 1;
+                            int vx = P.v(c.o.var_lb + it.idx[0]) + __ffs((int)D0) - 1, vy = P.v(c.o.var_lb + it.idx[1]) + __ffs((int)D1) - 1;
                             if (vx != 1 && vy != 1) lfail = true;
                         }
                     } else {
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                         if (it.arity < 3) D2 = 1u;
                         if (it.arity < 4) D3 = 1u;
                         uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                        const uint32_t *tab = c.tables + it.toff;
+                        const int tab = c.o.tables + it.toff;
                         unsigned nev = 0;
                         for (uint32_t m3 = D3; m3; m3 &= m3 - 1) {
                             const int b3 = __ffs((int)m3) - 1;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                                 const int base = it.r1 * (b2 + it.r2 * b3);
                                 for (uint32_t m1 = D1; m1; m1 &= m1 - 1) {
                                     const int b1 = __ffs((int)m1) - 1;
-                                    const uint32_t row = tab[base + b1] & D0;
+                                    const uint32_t row = (uint32_t)P.v(tab + base + b1) & D0;
                                     nev++;
                                     if (row) {
                                         s0 |= row;
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                 while (cm) {
                     int l = __ffsll((long long)cm) - 1;
                     cm &= cm - 1;
-                    if (lane < S.iw) dirtyw |= c.itemrows[S.itemrows_off + (q * 64 + l) * S.iw + lane];
+                    if (lane < S.iw) dirtyw |= (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (q * 64 + l) * S.iw + lane);
                 }
             }
             if (++guard > (1u << 20)) {
@@ -690,11 +695,11 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         int b = __ffs((int)word) - 1;
         int item = wl * 32 + b;
         if (lane == wl) dirtyw &= ~(1u << b);
-        const int ibase = (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
-        const int ipoint = kload(c.items, ibase + 1), icon = kload(c.items, ibase + 2);
+        const int ibase = c.o.items + (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
+        const int ipoint = P.u(ibase + 1), icon = P.u(ibase + 2);
         ConDesc C;
-        load_con(c, icon, C);
-        consistent = revise_point<DR>(c, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
+        load_con<L>(c, P, icon, C);
+        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
         if (++guard > (1u << 20)) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             consistent = false;
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         int mid = lo + (hi - lo) / 2;
         uint32_t lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
         uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + ro * CST], 2u);
+        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out0 + ro * CST], 2u);
         pos = rflu(pos);
         if (pos + 2 > a.out_cap) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -751,16 +756,16 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     if (!S.self_loop) {
         int fv = 0;
         if (lane < S.nfirst) {
-            int v = c.firstvars[S.first_off + lane];
+            int v = P.v(c.o.firstvars + S.first_off + lane);
             fv = v;
         }
         uint32_t fd = dom.gather(fv);  // time-0 word of that variable
-        int fval = (lane < S.nfirst) ? c.var_lb[fv] + __ffs((int)fd) - 1 : 0;
+        int fval = (lane < S.nfirst) ? P.v(c.o.var_lb + fv) + __ffs((int)fd) - 1 : 0;
         next_set = -1;
         for (int t = 0; t < S.trans_count && next_set < 0; t++) {
-            int voff = rfl(c.trans[S.trans_begin + t].vals_off);
-            bool ne = lane < S.nfirst && c.transvals[voff + lane] != fval;
-            if (!__ballot(ne)) next_set = rfl(c.trans[S.trans_begin + t].next_set);
+            int voff = P.u(c.o.trans + (S.trans_begin + t) * 2);
+            bool ne = lane < S.nfirst && P.v(c.o.transvals + voff + lane) != fval;
+            if (!__ballot(ne)) next_set = P.u(c.o.trans + (S.trans_begin + t) * 2 + 1);
         }
         if (next_set < 0) {
             // unknown transition: park the node again and tell the host which translation is needed
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
             uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&c.ctl[L.out0 + ro * CST], 1u);
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out0 + ro * CST], 1u);
             pos = rflu(pos);
             if (pos + 1 > a.out_cap) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -787,20 +792,20 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
             return;
         }
     }
-    const uint32_t next_tag = (uint32_t)rfl(c.sets[next_set].tag);
+    const uint32_t next_tag = (uint32_t)P.u(c.o.sets + next_set * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
     // (2) signature (:812-837): signature variables in queue order, then one sticky flag per until
     uint32_t new_expire = expire;
     uint32_t kw = 0;  // lane j holds key word j: [tag, sig...]
     {
         int sv = 0;
-        if (lane >= 1 && lane <= c.n_sig) sv = c.sig_vars[lane - 1];
+        if (lane >= 1 && lane <= c.n_sig) sv = P.v(c.o.sig_vars + lane - 1);
         uint32_t sd = dom.gather(sv);
-        if (lane >= 1 && lane <= c.n_sig) kw = (uint32_t)(c.var_lb[sv] + __ffs((int)sd) - 1);
+        if (lane >= 1 && lane <= c.n_sig) kw = (uint32_t)(P.v(c.o.var_lb + sv) + __ffs((int)sd) - 1);
         for (int u = 0; u < c.n_until_cons; u++) {
-            int y = rfl(c.until_y[u]);
+            int y = P.u(c.o.until_y + u);
             uint32_t DY = dom.get(y);
             bool ex = (expire >> u) & 1u;
-            if (!ex && rfl(c.var_lb[y]) + __ffs((int)DY) - 1 == 1) {
+            if (!ex && P.u(c.o.var_lb + y) + __ffs((int)DY) - 1 == 1) {
                 ex = true;
                 new_expire |= 1u << u;
             }
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
     const int owner = (int)((h >> 40) % (unsigned)c.world);
     // (4) candidate record: header, signature, edge label, time-advanced block
     uint32_t pos = 0;
-    if (lane == 0) pos = atomicAdd(&c.ctl[L.cand0 + (owner * R + ro) * CST], 1u);
+    if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (owner * R + ro) * CST], 1u);
     pos = rflu(pos);
     if (pos + 1 > a.cand_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int idx = q * 64 + lane;
-        if (idx < c.N) vals[idx] = (uint32_t)(c.var_lb[idx] + __ffs((int)dom.r[q]) - 1);  // Edge::values
+        if (idx < c.N) vals[idx] = (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1);  // Edge::values
     }
     // variableAdvanceOneTimeStep (variable.cpp:94-108): point p <- point p+1, last point <- [lb,ub]
 #pragma unroll
@@ -839,10 +844,31 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a) {
         uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
         if (idx < c.NK) {
             int p = idx / c.N, v = idx - p * c.N;
-            blk[idx] = (p + 1 < c.K) ? shifted : c.var_init[v];
+            blk[idx] = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
         }
     }
     if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+}
+
+// Each workgroup first stages the program image into LDS (when L), then its four wavefronts
+// loop over the launch's node slots with a grid stride.
+template <int DR, bool L>
+__global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    if (L) {
+        const uint4 *src = (const uint4 *)c.img;
+        uint4 *dst = (uint4 *)smem;
+        for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
+        __syncthreads();
+    }
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
+    int *lds_vals = smem + img_words + wib * per_wave;
+    int *lds_stk = lds_vals + kMaxLowVars * 64;
+    Img<L> P{L ? (const uint32_t *)smem : c.img};
+    const int total_waves = gridDim.x * 4;
+    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L>(c, a, P, gw, lane, lds_vals, lds_stk);
 }
 
 // ------------------------------------------------------------------ k_commit
@@ -950,7 +976,7 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     // new state: open its first search node (the successor block travelled with the candidate)
     int set = -1;
     for (int s = 0; s < c.nsets && set < 0; s++)
-        if ((uint32_t)rfl(c.sets[s].tag) == tag) set = s;
+        if ((uint32_t)kload(c.img, c.o.sets + s * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = s;
     if (set < 0) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
         return;
@@ -1055,12 +1081,12 @@ struct stcsp_engine {
     CtlLayout L{1};
     size_t lds_bytes = 0;
     int chunk_r = 0;  // max nodes taken per region per launch
+    int max_blocks = 256 * 8;  // k_expand grid cap (workgroups)
 
     DevBuf<int> d_var_lb, d_arr_off, d_arr_data, d_sig_vars, d_until_y, d_scope, d_code, d_firstvars, d_transvals, d_miss;
     DevBuf<uint32_t> d_var_init, d_varcons, d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack;
-    DevBuf<ItemDesc> d_items;
-    DevBuf<uint32_t> d_itemrows, d_tables;
-    DevBuf<int> d_strides;
+    DevBuf<uint32_t> d_img;
+    bool img_in_lds = false;
     DevBuf<SetDesc> d_sets;
     DevBuf<ConDesc> d_cons;
     DevBuf<TransDesc> d_trans;
@@ -1118,34 +1144,52 @@ struct stcsp_engine {
     int upload_program() {
         int rc = mgr.compile(prog);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
-        HIPCHK(d_sets.upload(prog.sets));
-        HIPCHK(d_cons.upload(prog.cons));
-        HIPCHK(d_scope.upload(prog.scope));
+        // one contiguous image; every section starts on a 16-byte boundary
+        std::vector<uint32_t> img;
+        ImgOff o{};
+        auto put = [&](const void *data, size_t bytes) {
+            while (img.size() & 3) img.push_back(0u);
+            int off = (int)img.size();
+            size_t words = (bytes + 3) / 4;
+            img.resize(img.size() + words, 0u);
+            if (bytes) memcpy(img.data() + off, data, bytes);
+            return off;
+        };
+        std::vector<uint32_t> init(ctx.N);
+        for (int v = 0; v < ctx.N; v++) {
+            int w = mgr.ub[v] - mgr.lb[v] + 1;
+            init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
+        }
+        o.sets = put(prog.sets.data(), prog.sets.size() * sizeof(SetDesc));
+        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
+        o.scope = put(prog.scope.data(), prog.scope.size() * 4);
+        o.strides = put(prog.strides.data(), prog.strides.size() * 4);
+        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
+        o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
+        o.var_lb = put(mgr.lb.data(), mgr.lb.size() * 4);
+        o.var_init = put(init.data(), init.size() * 4);
+        o.sig_vars = put(mgr.sig_vars.data(), mgr.sig_vars.size() * 4);
+        o.until_y = put(mgr.until_y.data(), mgr.until_y.size() * 4);
+        o.firstvars = put(prog.firstvars.data(), prog.firstvars.size() * 4);
+        o.trans = put(prog.trans.data(), prog.trans.size() * sizeof(TransDesc));
+        o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
+        o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
+        o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
+        while (img.size() & 3) img.push_back(0u);
+        o.words = (int)img.size();
+        HIPCHK(d_img.upload(img));
         HIPCHK(d_code.upload(prog.code));
-        HIPCHK(d_firstvars.upload(prog.firstvars));
-        HIPCHK(d_trans.upload(prog.trans));
-        HIPCHK(d_transvals.upload(prog.transvals));
-        HIPCHK(d_varcons.upload(prog.varcons));
-        HIPCHK(d_items.upload(prog.items));
-        HIPCHK(d_itemrows.upload(prog.itemrows));
-        HIPCHK(d_tables.upload(prog.tables));
-        HIPCHK(d_strides.upload(prog.strides));
-        ctx.items = d_items.p;
-        ctx.itemrows = d_itemrows.p;
-        ctx.tables = d_tables.p;
-        ctx.strides = d_strides.p;
-        ctx.sets = d_sets.p;
-        ctx.cons = d_cons.p;
-        ctx.scope = d_scope.p;
+        ctx.img = d_img.p;
+        ctx.o = o;
         ctx.code = d_code.p;
-        ctx.firstvars = d_firstvars.p;
-        ctx.trans = d_trans.p;
-        ctx.transvals = d_transvals.p;
-        ctx.varcons = d_varcons.p;
         ctx.nsets = (int)prog.sets.size();
         ctx.stack_slots = prog.max_stack + 2;
-        lds_bytes = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 63) & ~63)) * sizeof(int);
-        if (lds_bytes > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
+        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 63) & ~63)) * sizeof(int);
+        if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
+        // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
+        img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
+        if (const char *ev = getenv("STCSP_IMG_LDS")) img_in_lds = img_in_lds && atoi(ev) != 0;  // tuning switch
+        lds_bytes = scratch + (img_in_lds ? (size_t)o.words * 4 : 0);
         return STCSP_OK;
     }
 
@@ -1185,23 +1229,8 @@ struct stcsp_engine {
         ctx.rank = opt.rank;
         DR = (N * K + 63) / 64;
         if (DR == 3) DR = 4;
-        std::vector<uint32_t> init(N);
-        for (int v = 0; v < N; v++) {
-            int w = mgr.ub[v] - mgr.lb[v] + 1;
-            init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
-        }
-        HIPCHK(d_var_lb.upload(mgr.lb));
-        HIPCHK(d_var_init.upload(init));
-        HIPCHK(d_arr_off.upload(mgr.array_off));
         HIPCHK(d_arr_data.upload(mgr.array_data));
-        HIPCHK(d_sig_vars.upload(mgr.sig_vars));
-        HIPCHK(d_until_y.upload(mgr.until_y));
-        ctx.var_lb = d_var_lb.p;
-        ctx.var_init = d_var_init.p;
-        ctx.arr_off = d_arr_off.p;
         ctx.arr_data = d_arr_data.p;
-        ctx.sig_vars = d_sig_vars.p;
-        ctx.until_y = d_until_y.p;
         rc = upload_program();
         if (rc != STCSP_OK) return rc;
         // pools
@@ -1376,8 +1405,13 @@ struct stcsp_engine {
 
     template <int DRT>
     void launch_expand(const ExpandArgs &a, int maxtake) {
-        int waves = R * maxtake;
-        hipLaunchKernelGGL((k_expand<DRT>), dim3((waves + 3) / 4), dim3(256), lds_bytes, stream, ctx, a);
+        const int slots = R * maxtake;
+        // enough workgroups to fill the chip a few times over; wavefronts grid-stride over the slots
+        const int blocks = std::min((slots + 3) / 4, max_blocks);
+        if (img_in_lds)
+            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(blocks), dim3(256), lds_bytes, stream, ctx, a, slots);
+        else
+            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(blocks), dim3(256), lds_bytes, stream, ctx, a, slots);
     }
 
     int service_misses() {

@@ -112,3 +112,31 @@ def test_engine_matches_oracle_text(stcsp, RefOracle, name):
     e = stcsp.Engine(m)
     ae, _ = finish(e, e.solve())
     assert ae.canonical() == ao.canonical()
+
+
+@pytest.mark.parametrize("shape", [(8, 4, 14, 2, 1), (16, 8, 95, 4, 3), (16, 8, 88, 4, 4), (16, 8, 80, 4, 5)])
+def test_engine_synthetic_parity(stcsp, RefOracle, shape):
+    """BASELINE.json config 4 family (random extensional binary constraints through `arr`
+    lookups, some under `next`) at shapes the CPU oracle finishes: these instances exercise the
+    FAILING branches the shipped examples (fail = 0) never hit."""
+    m = stcsp.Model(text=stcsp.instances.synthetic(*shape))
+    o = RefOracle(m)
+    ao, _ = finish(o, o.solve())
+    e = stcsp.Engine(m)
+    r = e.solve()
+    ae, _ = finish(e, r)
+    assert ae.canonical() == ao.canonical()
+    assert r.counters.fails > 0 or shape[0] == 8
+
+
+def test_engine_synthetic_64x32_timebox(stcsp):
+    """64 vars x |D| = 32, 602 point + 6 stream constraints: a time-boxed throughput run (no
+    implementation reaches a leaf quickly). Exercises 4-register blocks, the global-memory
+    program path, the chunked depth-first frontier, arena growth and the time limit."""
+    m = stcsp.Model(text=stcsp.instances.synthetic(64, 32, 602, 6, 20261003))
+    assert m.n_vars == 70
+    e = stcsp.Engine(m, time_limit_s=2.0)
+    r = e.solve()
+    assert r.truncated == 1
+    assert r.counters.search_nodes > 1_000_000
+    assert r.counters.fails > 0
