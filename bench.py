@@ -153,6 +153,12 @@ def main():
         per_launch_bytes = alg_bytes / max(k_launches, 1)
         avg_launch_s = k_time / max(k_launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM traffic of the same kernel from the committed PMC passes (bench.py cannot collect
+        # counters itself): profiles/r01_p14_traffic.json, per launch, gfx950-corrected
+        traffic = None
+        tf = REPO / "profiles" / "r01_p14_traffic.json"
+        if args.workload == WORKLOAD and world == 1 and tf.exists():
+            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch_corrected"]
         out = {
             "metric": "search-tree nodes/sec on partialorder_14.csp",
             "value": nodes / elapsed,
@@ -174,7 +180,7 @@ def main():
                                     "wavefront_revisions": wrevs / max(nodes, 1), "sweeps": sweeps / max(nodes, 1)},
                        "sharding": "none" if world == 1 else f"state-owner x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_expand",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_expand",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,
                          "launches": k_launches, "bytes_per_node": b_node, "bytes_per_leaf": b_leaf,
                          "kernel_time_share": k_time / elapsed if elapsed > 0 else None},
