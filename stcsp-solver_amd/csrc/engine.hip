@@ -524,6 +524,11 @@ __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t
     }
 }
 
+template <int DR>
+__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, uint32_t kw,
+                            unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
+                            const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot);
+
 // ------------------------------------------------------------------ k_expand
 // expand ONE open node (slot `gw` of this launch) with one wavefront
 template <int DR, bool L>
@@ -818,7 +823,28 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
     h = mix_final(h);
     const int owner = (int)((h >> 40) % (unsigned)c.world);
-    // (4) candidate record: header, signature, edge label, time-advanced block
+    // edge label (Edge::values) and the time-advanced block (variableAdvanceOneTimeStep,
+    // variable.cpp:94-108: point p <- point p+1, last point <- [lb,ub]), lane-striped
+    uint32_t evals[DR], nblk[DR];
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        evals[q] = idx < c.N ? (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1) : 0u;
+        uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
+        uint32_t nb = 0;
+        if (idx < c.NK) {
+            int p = idx / c.N, v = idx - p * c.N;
+            nb = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
+        }
+        nblk[q] = nb;
+    }
+    if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+    if (c.world == 1) {
+        // unsharded: commit right here, the leaf's data never leaves the registers
+        commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, kw, h, h0, h1, next_set, next_tag, new_expire, evals, nblk, gw);
+        return;
+    }
+    // (4) sharded: candidate record for the owner: header, signature, edge label, block
     uint32_t pos = 0;
     if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (owner * R + ro) * CST], 1u);
     pos = rflu(pos);
@@ -835,19 +861,9 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int idx = q * 64 + lane;
-        if (idx < c.N) vals[idx] = (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1);  // Edge::values
+        if (idx < c.N) vals[idx] = evals[q];
+        if (idx < c.NK) blk[idx] = nblk[q];
     }
-    // variableAdvanceOneTimeStep (variable.cpp:94-108): point p <- point p+1, last point <- [lb,ub]
-#pragma unroll
-    for (int q = 0; q < DR; q++) {
-        int idx = q * 64 + lane;
-        uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
-        if (idx < c.NK) {
-            int p = idx / c.N, v = idx - p * c.N;
-            blk[idx] = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
-        }
-    }
-    if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
 }
 
 // Each workgroup first stages the program image into LDS (when L), then its four wavefronts
@@ -871,35 +887,21 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a, int n_slots
     for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L>(c, a, P, gw, lane, lds_vals, lds_stk);
 }
 
-// ------------------------------------------------------------------ k_commit
-__global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const long long gw = (long long)blockIdx.x * 4 + wib;
-    const int r = (int)(gw % R);
+// ------------------------------------------------------------------ commit
+// Lookup-or-insert the state (set tag, signature) held lane-striped in `kw` (lane j = key word j),
+// append the edge record and, for a new state, open its first search node.  Used by k_expand
+// directly (unsharded: the leaf's data is still in registers) and by k_commit (sharded: the data
+// arrives as candidate records).  vals / blk are lane-striped like the domain block.
+// Role of vertexTableGetVertex / vertexNew + vertexTableAddVertex / edgeNew + vertexAddEdge
+// (reference src/graph.cpp:14-38, 78-89, 108-123).
+template <int DR>
+__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, uint32_t kw,
+                            unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
+                            const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot) {
     const CtlLayout L(c.world);
     uint32_t *misc = c.ctl + L.misc0;
-    const uint32_t *rec;
-    int ro = r;  // cursor shard for this wavefront's outputs (edge record, new node)
-    if (a.regions) {
-        long long i = gw / R;
-        uint32_t cnt = c.ctl[a.cand_cursor_base + r * CST];
-        if (i >= (long long)cnt) return;
-        rec = a.cand_base + ((size_t)r * a.cand_cap + (size_t)i) * c.CS;
-        ro = (int)((i + r) % R);
-    } else {
-        if (gw >= a.total) return;
-        rec = a.cand_base + (size_t)gw * c.CS;
-    }
-    uint32_t hw = lane < 6 ? rec[lane] : 0u;  // one coalesced header read
-    const uint32_t s0 = rdlane(hw, 0), s1 = rdlane(hw, 1), tag = rdlane(hw, 2), expire = rdlane(hw, 3);
-    const unsigned long long h = ((unsigned long long)rdlane(hw, 5) << 32) | rdlane(hw, 4);  // computed by k_expand
-    uint32_t kw = 0;
-    if (lane == 0) kw = tag;
-    if (lane >= 1 && lane <= c.sig_len) kw = rec[kCandHdr + lane - 1];
     const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
     uint32_t pos = (uint32_t)h & c.slot_mask;
-
-    // lookup-or-insert (vertexTableGetVertex / vertexNew + vertexTableAddVertex)
     uint32_t idx = 0;
     bool is_new = false;
     for (unsigned probes = 0;; probes++) {
@@ -970,30 +972,72 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     }
     uint32_t *er = c.edges + ((size_t)ro * c.edge_cap + e) * c.ES;
     if (lane < 4) er[lane] = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? idx : 0u));
-    const uint32_t *vals = rec + kCandHdr + c.sig_len;
-    for (int v = lane; v < c.N; v += 64) er[4 + v] = vals[v];
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int k = q * 64 + lane;
+        if (k < c.N) er[4 + k] = vals[q];
+    }
     if (!is_new) return;
-    // new state: open its first search node (the successor block travelled with the candidate)
-    int set = -1;
-    for (int s = 0; s < c.nsets && set < 0; s++)
-        if ((uint32_t)kload(c.img, c.o.sets + s * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = s;
+    // new state: open its first search node
     if (set < 0) {
-        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
-        return;
+        for (int t = 0; t < c.nsets && set < 0; t++)
+            if ((uint32_t)kload(c.img, c.o.sets + t * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = t;
+        if (set < 0) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
+            return;
+        }
     }
     uint32_t np = 0;
     if (lane == 0) np = atomicAdd(&c.ctl[L.out0 + ro * CST], 1u);
     np = rflu(np);
-    if (np + 1 > a.out_cap) {
+    if (np + 1 > out_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
         return;
     }
-    uint32_t *dst = a.out_base + ((size_t)ro * a.out_cap + np) * c.NS;
+    uint32_t *dst = out_base + ((size_t)ro * out_cap + np) * c.NS;
     const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | idx;
     if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)set : expire));
-    const uint32_t *blk = vals + c.N;
-    for (int k = lane; k < c.NK; k += 64) dst[4 + k] = blk[k];
-    if (lane == 0) add_stats(c, (int)(gw & 0x7fffffff), ST_NEWSTATES, 1);
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int k = q * 64 + lane;
+        if (k < c.NK) dst[4 + k] = blk[q];
+    }
+    if (lane == 0) add_stats(c, stat_slot, ST_NEWSTATES, 1);
+}
+
+// ------------------------------------------------------------------ k_commit (sharded runs)
+template <int DR>
+__global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const long long gw = (long long)blockIdx.x * 4 + wib;
+    const int r = (int)(gw % R);
+    const uint32_t *rec;
+    int ro = r;  // cursor shard for this wavefront's outputs (edge record, new node)
+    if (a.regions) {
+        long long i = gw / R;
+        uint32_t cnt = c.ctl[a.cand_cursor_base + r * CST];
+        if (i >= (long long)cnt) return;
+        rec = a.cand_base + ((size_t)r * a.cand_cap + (size_t)i) * c.CS;
+        ro = (int)((i + r) % R);
+    } else {
+        if (gw >= a.total) return;
+        rec = a.cand_base + (size_t)gw * c.CS;
+    }
+    uint32_t hw = lane < 6 ? rec[lane] : 0u;  // one coalesced header read
+    const uint32_t s0 = rdlane(hw, 0), s1 = rdlane(hw, 1), tag = rdlane(hw, 2), expire = rdlane(hw, 3);
+    const unsigned long long h = ((unsigned long long)rdlane(hw, 5) << 32) | rdlane(hw, 4);  // computed by k_expand
+    uint32_t kw = 0;
+    if (lane == 0) kw = tag;
+    if (lane >= 1 && lane <= c.sig_len) kw = rec[kCandHdr + lane - 1];
+    const uint32_t *pv = rec + kCandHdr + c.sig_len, *pb = pv + c.N;
+    uint32_t vals[DR], blk[DR];
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int k = q * 64 + lane;
+        vals[q] = k < c.N ? pv[k] : 0u;
+        blk[q] = k < c.NK ? pb[k] : 0u;
+    }
+    commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, kw, h, s0, s1, -1, tag, expire, vals, blk, (int)(gw & 0x7fffffff));
 }
 
 // gather the R regions of one owner's outbox into a contiguous array (for the all-to-all)
@@ -1477,18 +1521,7 @@ struct stcsp_engine {
         HIPCHK(hipGetLastError());
         if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
         expand_launches++;
-        if (commit_local) {
-            CommitArgs ca{};
-            ca.cand_base = d_cand.p;
-            ca.cand_cap = cand_cap;
-            ca.regions = 1;
-            ca.cand_cursor_base = L.cand0;
-            ca.out_base = a.out_base;
-            ca.out_cap = a.out_cap;
-            int waves = R * maxtake;
-            hipLaunchKernelGGL(k_commit, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, ca);
-            HIPCHK(hipGetLastError());
-        }
+        (void)commit_local;  // unsharded engines commit inside k_expand (fused)
         rc = read_ctl();
         if (rc != STCSP_OK) return rc;
         levels++;
@@ -1642,7 +1675,14 @@ struct stcsp_engine {
         ca.total = count;
         ca.out_base = d_arena.p + T.base;
         ca.out_cap = T.cap;
-        hipLaunchKernelGGL(k_commit, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, ctx, ca);
+        {
+            dim3 grid((unsigned)((count + 3) / 4)), block(256);
+            switch (DR) {
+                case 1: hipLaunchKernelGGL((k_commit<1>), grid, block, 0, stream, ctx, ca); break;
+                case 2: hipLaunchKernelGGL((k_commit<2>), grid, block, 0, stream, ctx, ca); break;
+                default: hipLaunchKernelGGL((k_commit<4>), grid, block, 0, stream, ctx, ca); break;
+            }
+        }
         HIPCHK(hipGetLastError());
         rc = read_ctl();
         if (rc != STCSP_OK) return rc;
