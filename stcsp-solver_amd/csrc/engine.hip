@@ -55,20 +55,43 @@ constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
 constexpr int kStatWords = 16;
-enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED };
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
+       ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL };
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
 // control block (u32 words; every cursor on its own 64-byte line)
 struct CtlLayout {
-    int out0, cand0, edge0, misc0, words;
+    int out0, cand0, edge0, misc0, words;  // out0: TWO sets of R cursors (round parity)
     __host__ __device__ CtlLayout(int world) {
         out0 = 0;
-        cand0 = R * CST;
+        cand0 = 2 * R * CST;
         edge0 = cand0 + world * R * CST;
         misc0 = edge0 + R * CST;
         words = misc0 + 8 * CST;
     }
+    __host__ __device__ int out(int parity, int r) const { return out0 + (parity * R + r) * CST; }
+};
+
+// The frontier bookkeeping lives on the device: the last workgroup of every k_expand launch
+// accounts the round (finalize_round) and plans the next one (plan_next), so the host enqueues
+// bursts of rounds and synchronises once per burst.
+constexpr int kMaxSegments = 4096;
+enum PlanStatus : int { PS_RUN = 0, PS_DONE, PS_NEED_ARENA, PS_NEED_EDGES, PS_NEED_STATES, PS_NEED_TABLE, PS_HOST, PS_OUTBOX_FULL, PS_STACK_FULL };
+struct DevSegment {
+    unsigned long long base;  // word offset into the arena
+    unsigned cap;             // node slots per region
+    int count[R];
+    int pad;
+};
+struct Plan {
+    int status, parity, nslots, sp;
+    int take[R], count[R];
+    unsigned long long in_base, out_base, arena_top, arena_words, slot_cap;
+    unsigned in_cap, out_cap, edge_cap, state_cap, cand_cap, done_blocks;
+    int chunk_r, world;
+    long long rounds, open_total;
+    DevSegment stack[kMaxSegments];
 };
 enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
 enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
@@ -98,27 +121,24 @@ struct Ctx {
     int *miss;
     int miss_cap;
     unsigned long long *stats;
+    Plan *plan;
+    uint32_t *arena;
+    uint32_t *cand;  // outbox [owner][region] x cand_cap records (sharded runs)
 };
 
-struct ExpandArgs {
+struct ExpandArgs {  // per-round view, read from the device plan by every wavefront
     const uint32_t *in_base;
     uint32_t in_cap;
     uint32_t *out_base;
     uint32_t out_cap;
     uint32_t *cand_base;
     uint32_t cand_cap;
-    int take[R];
-    int count[R];
+    int parity;
 };
 
 struct CommitArgs {
-    const uint32_t *cand_base;  // regions of owner == rank (regions != 0) or a contiguous array
-    uint32_t cand_cap;
-    int regions;
-    long long total;  // contiguous mode
-    int cand_cursor_base;  // ctl word index of the owner's cursors (regions mode)
-    uint32_t *out_base;
-    uint32_t out_cap;
+    const uint32_t *cand_base;  // contiguous array of candidate records
+    long long total;
 };
 
 // ------------------------------------------------------------------ device helpers
@@ -178,8 +198,14 @@ struct Dom {
     }
 };
 
+#ifdef STCSP_PHASES
+#define PHASE_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define PHASE_NOW() 0ull
+#endif
 struct WaveStats {
     unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
+    unsigned long long cyc_sweep = 0, cyc_wave = 0;
     unsigned long long evals = 0;
 };
 
@@ -274,104 +300,103 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_val
     }
 }
 
-// Enforce one point constraint at one time point: afterwards every remaining value of every
-// scope variable has a supporting tuple (generalised arc consistency on this constraint; the
-// reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
-// Returns false when a domain is wiped out. `dirty` rows of changed variables are OR-ed in.
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
+// position of the k-th (0-based) set bit of m, branch-free (k < popcount(m))
+__device__ __forceinline__ int select_kth_fast(uint32_t m, int k) {
+    int pos = 0, cnt;
+    cnt = __popc(m & 0xffffu);
+    if (k >= cnt) { k -= cnt; pos += 16; m >>= 16; }
+    cnt = __popc(m & 0xffu);
+    if (k >= cnt) { k -= cnt; pos += 8; m >>= 8; }
+    cnt = __popc(m & 0xfu);
+    if (k >= cnt) { k -= cnt; pos += 4; m >>= 4; }
+    cnt = __popc(m & 0x3u);
+    if (k >= cnt) { k -= cnt; pos += 2; m >>= 2; }
+    if (k >= (int)(m & 1u)) pos += 1;
+    return pos;
+}
+// x / d for 0 <= x < 64, 1 <= d <= 64 via one reciprocal (exact: (x + 0.5) / d is never within
+// 1/128 of an integer, far above float error)
+__device__ __forceinline__ int small_div(int x, int d) {
+    return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+
+// Enforce one point constraint at one time point: afterwards every remaining value of every
+// scope variable has a supporting tuple (generalised arc consistency on this constraint; the
+// reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
+// Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
 template <int DR, bool L>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
                              int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
-    uint32_t D = 0;
-    if (lane < s) {
-        var = G.v(c.o.scope + C.scope_off + lane);
-        }
-    D = dom.gather(p * c.N + var);
+    if (lane < s) var = G.v(c.o.scope + C.scope_off + lane);
+    uint32_t D = dom.gather(p * c.N + var);
     if (lane >= s) D = 0;
-    int n = lane < s ? __popc(D) : 1;
+    const int n = lane < s ? __popc(D) : 1;
     if (__ballot(lane < s && n == 0)) return false;
-    int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
+    const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
     const bool use_bitmap = C.bitmap_off >= 0;
     const int mystride = (use_bitmap && lane < s) ? G.v(c.o.strides + C.stride_off + lane) : 0;
-    int lane_part = 0;  // bitmap: this lane's tuple index contribution of the lane-enumerated variables
 
-    // --- split the scope: up to kMaxLowVars variables whose domain sizes multiply to <= 64 are
-    // enumerated ACROSS LANES (lane index = mixed-radix tuple index); the rest are wave-uniform
-    // per iteration (singletons, or "high" variables stepped by an odometer).
-    uint32_t varinfo = 0;  // lane j: 1 + slot if low
-    int stride = 1;        // lane j: radix stride if low
-    int pairbase = 0;      // lane j: first pair lane of low var j
+    // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
+    // multiply to <= 64 are enumerated ACROSS LANES (lane index = mixed-radix tuple index), the rest
+    // ("high") are stepped wave-uniformly by an odometer. Singletons are just constants.
+    uint32_t varinfo = 0;   // scope lane j: 1 + slot if low
+    int pairbase = 0;       // scope lane j: first pair lane of low var j
+    int pst = 1, pn = 1, pk = 0;  // pair lane: stride / radix / digit it stands for
+    int lane_part = 0;      // tuple lane: bitmap index contribution of the low variables
     int P = 1, nlow = 0, npairs = 0;
-    unsigned long long highmask = 0;
-    for (int j = 0; j < s; j++) {
-        int nj = (int)rdlane((uint32_t)n, j);
-        if (nj <= 1) continue;
+    unsigned long long highmask = 0, lowmask = 0;
+    int maxn = 1;
+    for (unsigned long long m = __ballot(lane < s && n > 1); m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const int nj = (int)rdlane((uint32_t)n, j);
         if (nlow < kMaxLowVars && P * nj <= 64) {
+            const uint32_t Dj = rdlane(D, j);
+            const int q = small_div(lane, P);
+            const int digit = q - nj * small_div(q, nj);
+            const int bitpos = select_kth_fast(Dj, digit);
+            lds_vals[nlow * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
+            if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
             if (lane == j) {
                 varinfo = 1 + nlow;
-                stride = P;
                 pairbase = npairs;
             }
+            if (lane >= npairs && lane < npairs + nj) {
+                pst = P;
+                pn = nj;
+                pk = lane - npairs;
+            }
+            lowmask |= 1ull << j;
             nlow++;
             P *= nj;
             npairs += nj;
         } else {
             highmask |= 1ull << j;
+            if (nj > maxn) maxn = nj;
         }
     }
     const bool active = lane < P;
-    // per-lane values of the low variables -> LDS (read back only by the same lane)
-    // and the 64-bit lane masks M[pair] = lanes whose digit of that variable equals k
-    uint32_t Mlo = 0, Mhi = 0;
-    {
-        unsigned long long lowmask = __ballot(varinfo != 0);
-        while (lowmask) {
-            int j = __ffsll((long long)lowmask) - 1;
-            lowmask &= lowmask - 1;
-            int slot = (int)rdlane(varinfo, j) - 1;
-            int st = (int)rdlane((uint32_t)stride, j);
-            int nj = (int)rdlane((uint32_t)n, j);
-            uint32_t Dj = rdlane(D, j);
-            int lbj = (int)rdlane((uint32_t)vlb, j);
-            int pb = (int)rdlane((uint32_t)pairbase, j);
-            int digit = (lane / st) % nj;
-            int bitpos = select_kth(Dj, digit);
-            lds_vals[slot * 64 + lane] = lbj + bitpos;
-            if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
-            for (int k = 0; k < nj; k++) {
-                unsigned long long m = __ballot(active && digit == k);
-                if (lane == pb + k) {
-                    Mlo = (uint32_t)m;
-                    Mhi = (uint32_t)(m >> 32);
-                }
-            }
-        }
-    }
     const bool pairlane = lane < npairs;
-    bool hit = false;       // pair lanes: this (low var, digit) has a support
-    uint32_t hs = 0;        // scope lanes (uniform vars): supported value bits
-    int digit_h = 0;        // scope lanes (high vars): odometer digit
-    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;
-    int curval = vlb + curbit;
-    const bool is_uniform = lane < s && varinfo == 0;
-    const bool is_high = (highmask >> lane) & 1ull;
-    int maxn = 1;
-    {
-        unsigned long long hm = highmask;
-        while (hm) {
-            int j = __ffsll((long long)hm) - 1;
-            hm &= hm - 1;
-            int nj = (int)rdlane((uint32_t)n, j);
-            if (nj > maxn) maxn = nj;
+    // pair lane (q,k): the set of tuple lanes whose digit of low variable q equals k is periodic
+    // in the lane index -- build it arithmetically (no ballots)
+    unsigned long long M = 0;
+    if (pairlane) {
+        M = ((1ull << pst) - 1ull) << (pk * pst);
+        int sh = pst * pn;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            if (sh < 64) M |= M << sh;
+            sh <<= 1;
         }
+        if (P < 64) M &= (1ull << P) - 1ull;
     }
     // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the
     // wave-uniform part of that product (the odometer range) is larger than the budget the
@@ -383,33 +408,38 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     {
         const unsigned long long budget = use_bitmap ? kBudgetBitmapIters : kBudgetCodeIters;
         unsigned long long total_hi = 1;
-        unsigned long long hm = highmask;
-        while (hm && total_hi <= budget) {
-            int j = __ffsll((long long)hm) - 1;
-            hm &= hm - 1;
-            total_hi *= (unsigned long long)rdlane((uint32_t)n, j);
-        }
+        for (unsigned long long hm = highmask; hm && total_hi <= budget; hm &= hm - 1)
+            total_hi *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)hm) - 1);
         if (total_hi > budget) {
             if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
             ws.skipped++;
             return true;
         }
     }
+    bool hit = false;   // pair lanes: this (low var, digit) has a support
+    uint32_t hs = 0;    // scope lanes (high vars): supported value bits
+    int digit_h = 0;    // scope lanes (high vars): odometer digit
+    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;
+    int curval = vlb + curbit;
+    const bool is_high = (highmask >> lane) & 1ull;
+    // bitmap index contribution of the singleton variables (constant for this revision)
+    int base_sum = 0;
+    if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit * mystride : 0);
     ws.revs++;
     ws.wave_revs++;
-    const unsigned nact = (unsigned)min(P, 64);
+    const unsigned nact = (unsigned)P;
     // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
     // value of every high variable appears once, so loose constraints finish here.
     // stage B: exhaustive odometer over the high variables, early exit once all is supported.
-    bool done = false;
+    bool any_sat = false;
     unsigned long long iters = 0;
     int stage_a_left = highmask ? maxn : 1;
     bool stage_b = false;
-    while (!done) {
+    for (;;) {
         if (stage_a_left > 0) {
             if (is_high) {
                 int it = maxn - stage_a_left;
-                curbit = select_kth(D, it % n);
+                curbit = select_kth_fast(D, it - n * small_div(it, n));
                 curval = vlb + curbit;
             }
             stage_a_left--;
@@ -423,69 +453,67 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         }
         int res;
         if (use_bitmap) {
-            int bit = lane_part + wave_sum(is_uniform ? curbit * mystride : 0);
+            int bit = lane_part + base_sum;
+            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+                const int j = __ffsll((long long)hm) - 1;
+                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
+            }
             res = active ? (int)(((uint32_t)G.v(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
         } else {
             res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
         }
         ws.evals += nact;
-        unsigned long long sm = __ballot(active && res != 0);
-        if (pairlane && ((((unsigned long long)Mhi << 32) | Mlo) & sm)) hit = true;
-        if (is_uniform && sm) hs |= 1u << curbit;
-        bool all = __ballot((pairlane && !hit) || (is_uniform && hs != D)) == 0;
-        if (all) break;
+        const unsigned long long sm = __ballot(active && res != 0);
+        if (sm) {
+            any_sat = true;
+            if (pairlane && (M & sm)) hit = true;
+            if (is_high) hs |= 1u << curbit;
+        }
+        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
         if (stage_a_left > 0) continue;
         if (!highmask) break;  // no high variables: the lanes covered the whole product
         if (!stage_b) continue;
         // advance the odometer (wave-uniform carry chain over the high variables)
-        unsigned long long hm = highmask;
         bool carry = true;
-        while (hm && carry) {
-            int j = __ffsll((long long)hm) - 1;
-            hm &= hm - 1;
+        for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
+            const int j = __ffsll((long long)hm) - 1;
             int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
-            int nj = (int)rdlane((uint32_t)n, j);
+            const int nj = (int)rdlane((uint32_t)n, j);
             if (dj == nj)
                 dj = 0;
             else
                 carry = false;
             if (lane == j) {
                 digit_h = dj;
-                curbit = select_kth(D, dj);
+                curbit = select_kth_fast(D, dj);
                 curval = vlb + curbit;
             }
         }
-        if (carry) done = true;  // wrapped around: product exhausted
+        if (carry) break;  // wrapped around: product exhausted
         if (++iters > (1ull << 22)) {
             if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             return false;
         }
     }
-    // --- write back: supported values only
-    unsigned long long hitmask = __ballot(pairlane && hit);
-    bool ok = true;
-    for (int j = 0; j < s; j++) {
-        uint32_t Dj = rdlane(D, j);
-        uint32_t info = rdlane(varinfo, j);
+    // --- write back. No satisfying tuple at all: wipe-out. Otherwise singletons are supported by
+    // construction and only the enumerated / stepped variables can lose values.
+    if (!any_sat) return false;
+    const unsigned long long hitmask = __ballot(pairlane && hit);
+    for (unsigned long long m = lowmask | highmask; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const uint32_t Dj = rdlane(D, j);
         uint32_t newD;
-        if (info) {
-            int pb = (int)rdlane((uint32_t)pairbase, j);
-            uint32_t dig = (uint32_t)(hitmask >> pb);
+        if ((lowmask >> j) & 1ull) {
+            const uint32_t dig = (uint32_t)(hitmask >> (int)rdlane((uint32_t)pairbase, j));
             bool keep = false;
-            if (lane < 32 && ((Dj >> lane) & 1u)) {
-                int rank = __popc(Dj & ((1u << lane) - 1u));
-                keep = (dig >> rank) & 1u;
-            }
+            if (lane < 32 && ((Dj >> lane) & 1u)) keep = (dig >> __popc(Dj & ((1u << lane) - 1u))) & 1u;
             newD = (uint32_t)__ballot(keep);
         } else {
             newD = rdlane(hs, j);
         }
-        if (newD == 0) {
-            ok = false;
-            break;
-        }
+        if (newD == 0) return false;
         if (newD != Dj) {
-            int vj = (int)rdlane((uint32_t)var, j);
+            const int vj = (int)rdlane((uint32_t)var, j);
             dom.set(p * c.N + vj, newD, lane);
             if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
         }
@@ -493,7 +521,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
     // its own changes (supports are whole tuples of surviving values)
     if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
-    return ok;
+    return true;
 }
 
 template <bool L>
@@ -525,7 +553,7 @@ __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t
 }
 
 template <int DR>
-__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, uint32_t kw,
+__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity, uint32_t kw,
                             unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
                             const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot);
 
@@ -534,15 +562,18 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
 template <int DR, bool L>
 __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
     const int r = gw % R, i = gw / R;
-    if (i >= a.take[r]) return;
+    const int take_r = kload(c.plan, (int)(offsetof(Plan, take) / 4) + r);
+    if (i >= take_r) return;
+    const int count_r = kload(c.plan, (int)(offsetof(Plan, count) / 4) + r);
     // outputs go to another cursor shard than the input's, or a subtree would stay in the region
     // of its root forever; for every i exactly one input region maps to each output region, so
     // an output region receives from at most max(take) wavefronts
     const int ro = (i + r) % R;
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
+    const unsigned long long t_start = PHASE_NOW();
 
-    const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(a.count[r] - 1 - i)) * c.NS;
+    const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
     Dom<DR> dom;
 #pragma unroll
     for (int q = 0; q < DR; q++) {
@@ -568,6 +599,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     // through an LDS copy (a Jacobi sweep); the remaining items are revised by the whole
     // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
     WaveStats ws;
+    const unsigned long long t_loaded = PHASE_NOW();
     int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
     uint32_t dirtyw = 0;
     if (lane < S.iw) {
@@ -587,6 +619,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     unsigned guard = 0;
     while (consistent) {
         if (__ballot((dirtyw & smallmask) != 0)) {
+            const unsigned long long t_sw = PHASE_NOW();
             // ---- lane-parallel sweep over the dirty small items
 #pragma unroll
             for (int q = 0; q < DR; q++) {
@@ -691,8 +724,10 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
                 consistent = false;
             }
+            ws.cyc_sweep += PHASE_NOW() - t_sw;
             continue;
         }
+        const unsigned long long t_wv = PHASE_NOW();
         unsigned long long dm = __ballot(dirtyw != 0);
         if (!dm) break;
         int wl = __ffsll((long long)dm) - 1;
@@ -705,6 +740,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         ConDesc C;
         load_con<L>(c, P, icon, C);
         consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
+        ws.cyc_wave += PHASE_NOW() - t_wv;
         if (++guard > (1u << 20)) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             consistent = false;
@@ -717,7 +753,13 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         add_stats(c, gw, ST_WAVEREVS, ws.wave_revs);
         add_stats(c, gw, ST_SWEEPS, ws.sweeps);
         add_stats(c, gw, ST_SKIPPED, ws.skipped);
+#ifdef STCSP_PHASES
+        add_stats(c, gw, ST_CYC_LOAD, t_loaded - t_start);
+        add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
+        add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
+#endif
     }
+    const unsigned long long t_prop = PHASE_NOW();
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
         return;
@@ -740,7 +782,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         int mid = lo + (hi - lo) / 2;
         uint32_t lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
         uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out0 + ro * CST], 2u);
+        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 2u);
         pos = rflu(pos);
         if (pos + 2 > a.out_cap) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -752,6 +794,12 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, cw2, expire, child, lane);
         child.set(bvar, D & ~lowmask, lane);
         store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, h0, h1, cw2, expire, child, lane);
+#ifdef STCSP_PHASES
+        if (lane == 0) {
+            add_stats(c, gw, ST_CYC_CLASSIFY, PHASE_NOW() - t_prop);
+            add_stats(c, gw, ST_CYC_TOTAL, PHASE_NOW() - t_start);
+        }
+#endif
         return;
     }
 
@@ -786,7 +834,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
             uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out0 + ro * CST], 1u);
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
             pos = rflu(pos);
             if (pos + 1 > a.out_cap) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -841,7 +889,15 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
     if (c.world == 1) {
         // unsharded: commit right here, the leaf's data never leaves the registers
-        commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, kw, h, h0, h1, next_set, next_tag, new_expire, evals, nblk, gw);
+        const unsigned long long t_cm = PHASE_NOW();
+        commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, kw, h, h0, h1, next_set, next_tag, new_expire, evals, nblk, gw);
+#ifdef STCSP_PHASES
+        if (lane == 0) {
+            add_stats(c, gw, ST_CYC_CLASSIFY, t_cm - t_prop);
+            add_stats(c, gw, ST_CYC_COMMIT, PHASE_NOW() - t_cm);
+            add_stats(c, gw, ST_CYC_TOTAL, PHASE_NOW() - t_start);
+        }
+#endif
         return;
     }
     // (4) sharded: candidate record for the owner: header, signature, edge label, block
@@ -866,12 +922,160 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     }
 }
 
+__device__ __forceinline__ uint32_t ald(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum64(long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// The round bookkeeping below is executed by ONE wavefront (lane r looks after cursor region r),
+// so that its global-memory reads go out in parallel: a handful of round trips per round.
+
+// Plan the next round from the top of the segment stack. Leaves status != PS_RUN when there is
+// nothing to do or the host has to act first (grow a pool, translate a constraint set, look at
+// an error).
+__device__ void plan_next(const Ctx &c, Plan *p, int lane) {
+    const CtlLayout L(c.world);
+    const bool rl = lane < R;
+    uint32_t flag = 0;
+    if (lane < 2) flag = ald(&c.ctl[L.misc0 + (lane == 0 ? MISC_ERROR : MISC_NMISS) * CST]);
+    if (__ballot(flag != 0)) {
+        if (lane == 0) p->status = PS_HOST;
+        return;
+    }
+    int sp = rfl(p->sp);
+    unsigned long long arena_top = p->arena_top;
+    int cnt = 0;
+    while (sp > 0) {  // drop exhausted segments from the top
+        cnt = rl ? p->stack[sp - 1].count[lane] : 0;
+        if (wave_sum64(cnt) != 0) break;
+        arena_top = p->stack[sp - 1].base;
+        sp--;
+    }
+    if (lane == 0) {
+        p->sp = sp;
+        p->arena_top = arena_top;
+    }
+    if (sp == 0) {
+        if (lane == 0) p->status = PS_DONE;
+        return;
+    }
+    const int chunk = p->chunk_r;
+    const int take = cnt < chunk ? cnt : chunk;
+    const int maxtake = wave_max(take);
+    const long long taken = wave_sum64(take);
+    const unsigned out_cap = 3u * (unsigned)maxtake;
+    int status = PS_RUN;
+    if (arena_top + (unsigned long long)R * out_cap * c.NS > p->arena_words) status = PS_NEED_ARENA;
+    const unsigned max_edges = (unsigned)wave_max(rl ? (int)ald(&c.ctl[L.edge0 + lane * CST]) : 0);
+    const unsigned long long ns = rflu(lane == 0 ? ald(&c.ctl[L.misc0 + MISC_NSTATES * CST]) : 0u);
+    if (status == PS_RUN && (unsigned long long)max_edges + maxtake > p->edge_cap) status = PS_NEED_EDGES;
+    if (status == PS_RUN && ns + taken > p->state_cap) status = PS_NEED_STATES;
+    if (status == PS_RUN && (ns + taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
+    if (status == PS_RUN && c.world > 1) {
+        int mc = 0;
+        for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
+        mc = wave_max(mc);
+        if ((unsigned long long)mc + chunk > p->cand_cap) status = PS_OUTBOX_FULL;
+    }
+    if (status != PS_RUN) {
+        if (lane == 0) p->status = status;
+        return;
+    }
+    const int parity = rfl(p->parity) ^ 1;
+    if (rl) {
+        p->take[lane] = take;
+        p->count[lane] = cnt;
+        c.ctl[L.out(parity, lane)] = 0u;
+    }
+    if (lane == 0) {
+        p->in_base = p->stack[sp - 1].base;
+        p->in_cap = p->stack[sp - 1].cap;
+        p->out_base = arena_top;
+        p->out_cap = out_cap;
+        p->nslots = R * maxtake;
+        p->parity = parity;
+        p->status = PS_RUN;
+    }
+}
+
+// Account a finished output segment: read its cursors, push it if non-empty.
+__device__ void push_output(const Ctx &c, Plan *p, bool consumed_input, int lane) {
+    const CtlLayout L(c.world);
+    const bool rl = lane < R;
+    const int parity = rfl(p->parity);
+    const int sp = rfl(p->sp);
+    const int tcount = rl ? (int)ald(&c.ctl[L.out(parity, lane)]) : 0;
+    const long long total = wave_sum64(tcount);
+    long long taken = 0;
+    if (consumed_input) {
+        const int tk = rl ? p->take[lane] : 0;
+        if (rl) p->stack[sp - 1].count[lane] -= tk;
+        taken = wave_sum64(tk);
+    }
+    if (lane == 0) p->open_total += total - taken;
+    if (total > 0) {
+        if (sp >= kMaxSegments) {
+            if (lane == 0) p->status = PS_STACK_FULL;
+            return;
+        }
+        if (rl) p->stack[sp].count[lane] = tcount;
+        if (lane == 0) {
+            p->stack[sp].base = p->out_base;
+            p->stack[sp].cap = p->out_cap;
+            p->sp = sp + 1;
+            p->arena_top = p->out_base + (unsigned long long)R * p->out_cap * c.NS;
+        }
+    }
+}
+
+__device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
+    push_output(c, p, true, lane);
+    if (lane == 0) p->rounds++;
+    __threadfence();
+    if (rfl(p->status) == PS_RUN) plan_next(c, p, lane);
+}
+
+__global__ void k_replan(Ctx c) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) plan_next(c, c.plan, threadIdx.x);
+}
+// sharded commit: open an output segment of `cap` slots per region / close it again
+__global__ void k_open_segment(Ctx c, unsigned cap) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        Plan *p = c.plan;
+        const CtlLayout L(c.world);
+        const int parity = rfl(p->parity) ^ 1;
+        if (threadIdx.x < R) c.ctl[L.out(parity, threadIdx.x)] = 0u;
+        if (threadIdx.x == 0) {
+            p->out_base = p->arena_top;
+            p->out_cap = cap;
+            p->parity = parity;
+        }
+    }
+}
+__global__ void k_close_segment(Ctx c) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) push_output(c, c.plan, false, threadIdx.x);
+}
+
 // Each workgroup first stages the program image into LDS (when L), then its four wavefronts
-// loop over the launch's node slots with a grid stride.
+// loop over the round's node slots with a grid stride; the last workgroup to finish accounts
+// the round and plans the next one.
 template <int DR, bool L>
-__global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a, int n_slots) {
+__global__ __launch_bounds__(256) void k_expand(Ctx c) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
+    if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int n_slots = kload(c.plan, (int)(offsetof(Plan, nslots) / 4));
+    // workgroups without a node slot leave at once; the ticket below counts the working ones only
+    if ((int)blockIdx.x * 4 >= n_slots) return;
+    const unsigned n_working = (unsigned)min((n_slots + 3) / 4, (int)gridDim.x);
     const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
     if (L) {
         const uint4 *src = (const uint4 *)c.img;
@@ -883,8 +1087,32 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a, int n_slots
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     Img<L> P{L ? (const uint32_t *)smem : c.img};
+    ExpandArgs a;
+    {
+        const Plan *p = c.plan;
+        a.in_base = c.arena + p->in_base;
+        a.in_cap = p->in_cap;
+        a.out_base = c.arena + p->out_base;
+        a.out_cap = p->out_cap;
+        a.cand_base = c.cand;
+        a.cand_cap = p->cand_cap;
+        a.parity = p->parity;
+    }
     const int total_waves = gridDim.x * 4;
     for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L>(c, a, P, gw, lane, lds_vals, lds_stk);
+    __syncthreads();
+    if (wib == 0) {
+        unsigned t = 0;
+        if (lane == 0) {
+            __threadfence();
+            t = atomicAdd(&c.plan->done_blocks, 1u);
+        }
+        if (rflu(t) == n_working - 1) {  // last working workgroup: every cursor of this round is final
+            if (lane == 0) c.plan->done_blocks = 0;
+            __threadfence();
+            finalize_round(c, c.plan, lane);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ commit
@@ -895,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_expand(Ctx c, ExpandArgs a, int n_slots
 // Role of vertexTableGetVertex / vertexNew + vertexTableAddVertex / edgeNew + vertexAddEdge
 // (reference src/graph.cpp:14-38, 78-89, 108-123).
 template <int DR>
-__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, uint32_t kw,
+__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity, uint32_t kw,
                             unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
                             const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot) {
     const CtlLayout L(c.world);
@@ -988,7 +1216,7 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
         }
     }
     uint32_t np = 0;
-    if (lane == 0) np = atomicAdd(&c.ctl[L.out0 + ro * CST], 1u);
+    if (lane == 0) np = atomicAdd(&c.ctl[L.out(parity, ro)], 1u);
     np = rflu(np);
     if (np + 1 > out_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
@@ -1010,19 +1238,10 @@ template <int DR>
 __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const long long gw = (long long)blockIdx.x * 4 + wib;
-    const int r = (int)(gw % R);
-    const uint32_t *rec;
-    int ro = r;  // cursor shard for this wavefront's outputs (edge record, new node)
-    if (a.regions) {
-        long long i = gw / R;
-        uint32_t cnt = c.ctl[a.cand_cursor_base + r * CST];
-        if (i >= (long long)cnt) return;
-        rec = a.cand_base + ((size_t)r * a.cand_cap + (size_t)i) * c.CS;
-        ro = (int)((i + r) % R);
-    } else {
-        if (gw >= a.total) return;
-        rec = a.cand_base + (size_t)gw * c.CS;
-    }
+    if (gw >= a.total) return;
+    const int ro = (int)(gw % R);  // cursor shard for this wavefront's outputs (edge record, new node)
+    const uint32_t *rec = a.cand_base + (size_t)gw * c.CS;
+    const Plan *p = c.plan;
     uint32_t hw = lane < 6 ? rec[lane] : 0u;  // one coalesced header read
     const uint32_t s0 = rdlane(hw, 0), s1 = rdlane(hw, 1), tag = rdlane(hw, 2), expire = rdlane(hw, 3);
     const unsigned long long h = ((unsigned long long)rdlane(hw, 5) << 32) | rdlane(hw, 4);  // computed by k_expand
@@ -1037,7 +1256,8 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
         vals[q] = k < c.N ? pv[k] : 0u;
         blk[q] = k < c.NK ? pb[k] : 0u;
     }
-    commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, kw, h, s0, s1, -1, tag, expire, vals, blk, (int)(gw & 0x7fffffff));
+    commit_core<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, kw, h, s0, s1, -1, tag, expire, vals, blk,
+                    (int)(gw & 0x7fffffff));
 }
 
 // gather the R regions of one owner's outbox into a contiguous array (for the all-to-all)
@@ -1138,8 +1358,9 @@ struct stcsp_engine {
     uint32_t *h_ctl = nullptr;  // pinned
     int *h_miss = nullptr;      // pinned
     uint32_t cand_cap = 0;
-    size_t arena_top = 0;
-    std::vector<Segment> stack;
+    DevBuf<Plan> d_plan;
+    Plan *h_plan = nullptr;  // pinned mirror of the plan header (everything before the stack)
+    int burst = 8;           // rounds enqueued per host synchronisation
     std::vector<uint32_t> edge_count = std::vector<uint32_t>(R, 0);
     uint32_t n_states = 0;
     bool begun = false, finished = false;
@@ -1166,6 +1387,7 @@ struct stcsp_engine {
             (void)hipEventDestroy(e.second);
         }
         if (h_ctl) (void)hipHostFree(h_ctl);
+        if (h_plan) (void)hipHostFree(h_plan);
         if (h_miss) (void)hipHostFree(h_miss);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1301,6 +1523,11 @@ struct stcsp_engine {
         if (opt.world > 1) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
         HIPCHK(d_arena.alloc((size_t)8 * R * chunk_r * ctx.NS));
+        HIPCHK(d_plan.alloc(1));
+        HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
+        if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_BLOCKS")) max_blocks = std::max(1, atoi(ev));
+        sync_ctx();
         return STCSP_OK;
     }
 
@@ -1338,51 +1565,73 @@ struct stcsp_engine {
         ctx.edge_cap = cap;
         return STCSP_OK;
     }
-    // make room for `incoming` more leaves/states before a launch, so kernels never overflow
-    int ensure_capacity(long long incoming, long long per_region) {
-        uint32_t max_edges = 0;
-        for (int r = 0; r < R; r++) max_edges = std::max(max_edges, edge_count[r]);
-        if ((long long)max_edges + per_region > (long long)ctx.edge_cap) {
-            uint64_t cap = ctx.edge_cap;
-            while ((long long)max_edges + per_region > (long long)cap) cap *= 2;
-            if (cap > 0x7fffffffull) return fail(STCSP_E_NOMEM, "edge log too large");
-            int rc = alloc_edges((uint32_t)cap);
-            if (rc != STCSP_OK) return rc;
-        }
-        if ((long long)n_states + incoming > (long long)ctx.state_cap) {
-            uint64_t cap = ctx.state_cap;
-            while ((long long)n_states + incoming > (long long)cap) cap *= 2;
-            if (cap > 0x7fffffffull) return fail(STCSP_E_NOMEM, "state pool too large");
-            int rc = alloc_states((uint32_t)cap);
-            if (rc != STCSP_OK) return rc;
-        }
-        if (((long long)n_states + incoming) * 2 > (long long)ctx.slot_mask + 1) {
-            uint64_t slots = (uint64_t)ctx.slot_mask + 1;
-            while (((long long)n_states + incoming) * 2 > (long long)slots) slots *= 2;
-            if (slots > (1ull << 31)) return fail(STCSP_E_NOMEM, "state table too large");
-            int rc = alloc_table((uint32_t)slots);
-            if (rc != STCSP_OK) return rc;
-            if (n_states) hipLaunchKernelGGL(k_rehash, dim3((n_states + 255) / 256), dim3(256), 0, stream, ctx, n_states);
-            HIPCHK(hipGetLastError());
-        }
+    void sync_ctx() {
+        ctx.plan = d_plan.p;
+        ctx.arena = d_arena.p;
+        ctx.cand = d_cand.p;
+    }
+    static constexpr size_t kPlanHeader = offsetof(Plan, stack);
+
+    // pool growth (between bursts, when the device plan asks for it)
+    int grow_edges() {
+        if (ctx.edge_cap > 0x3fffffffu) return fail(STCSP_E_NOMEM, "edge log too large");
+        int rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
+        return alloc_edges(ctx.edge_cap * 2);
+    }
+    int grow_states() {
+        if (ctx.state_cap > 0x3fffffffu) return fail(STCSP_E_NOMEM, "state pool too large");
+        int rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
+        return alloc_states(ctx.state_cap * 2);
+    }
+    int grow_table() {
+        uint64_t slots = ((uint64_t)ctx.slot_mask + 1) * 2;
+        if (slots > (1ull << 31)) return fail(STCSP_E_NOMEM, "state table too large");
+        int rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
+        rc = alloc_table((uint32_t)slots);
+        if (rc != STCSP_OK) return rc;
+        if (n_states) hipLaunchKernelGGL(k_rehash, dim3((n_states + 255) / 256), dim3(256), 0, stream, ctx, n_states);
+        HIPCHK(hipGetLastError());
         return STCSP_OK;
     }
-    int ensure_arena(size_t words_needed) {
-        if (arena_top + words_needed <= d_arena.n) return STCSP_OK;
-        size_t want = std::max(d_arena.n * 2, arena_top + words_needed);
+    int grow_arena(size_t min_words) {
+        size_t want = std::max(d_arena.n * 2, min_words);
         DevBuf<uint32_t> nb;
         if (nb.alloc(want) != hipSuccess) return fail(STCSP_E_NOMEM, "cannot grow the frontier arena to %zu MiB", want * 4 >> 20);
-        HIPCHK(hipMemcpyAsync(nb.p, d_arena.p, arena_top * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(nb.p, d_arena.p, (size_t)h_plan->arena_top * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
         std::swap(d_arena.p, nb.p);
         std::swap(d_arena.n, nb.n);
         return STCSP_OK;
     }
+    // push the host-side capacities into the device plan (after any growth)
+    int push_caps() {
+        sync_ctx();
+        h_plan->arena_words = d_arena.n;
+        h_plan->slot_cap = (unsigned long long)ctx.slot_mask + 1;
+        h_plan->edge_cap = ctx.edge_cap;
+        h_plan->state_cap = ctx.state_cap;
+        h_plan->cand_cap = cand_cap;
+        HIPCHK(hipMemcpyAsync(&d_plan.p->arena_words, &h_plan->arena_words, sizeof(unsigned long long) * 2, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(&d_plan.p->edge_cap, &h_plan->edge_cap, sizeof(unsigned) * 3, hipMemcpyHostToDevice, stream));
+        return STCSP_OK;
+    }
+    int read_plan() {
+        HIPCHK(hipMemcpyAsync(h_plan, d_plan.p, kPlanHeader, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        levels = h_plan->rounds;
+        return STCSP_OK;
+    }
+    int replan() {
+        hipLaunchKernelGGL(k_replan, dim3(1), dim3(64), 0, stream, ctx);
+        HIPCHK(hipGetLastError());
+        return STCSP_OK;
+    }
 
     int begin() {
         HIPCHK(hipSetDevice(device));
-        stack.clear();
-        arena_top = 0;
         std::fill(edge_count.begin(), edge_count.end(), 0u);
         n_states = 0;
         truncated = false;
@@ -1392,8 +1641,12 @@ struct stcsp_engine {
         seconds_expand_kernel = 0;
         expand_launches = 0;
         HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));
+        for (int i = 0; i < L.words; i++) h_ctl[i] = 0;
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
+        memset(h_plan, 0, sizeof(Plan));
+        h_plan->chunk_r = chunk_r;
+        h_plan->world = opt.world;
         if (opt.rank == 0) {
             // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
             // With an empty signature a leaf of set 0 must find it again, so the key is the plain
@@ -1417,16 +1670,18 @@ struct stcsp_engine {
                     int w = mgr.ub[v] - mgr.lb[v] + 1;
                     node[4 + p * ctx.N + v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
                 }
-            Segment s{};
-            s.base = 0;
-            s.cap = 1;
-            s.count[0] = 1;
-            int rc = ensure_arena((size_t)R * ctx.NS);
-            if (rc != STCSP_OK) return rc;
             HIPCHK(hipMemcpyAsync(d_arena.p, node.data(), ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            arena_top = (size_t)R * 1 * ctx.NS;
-            stack.push_back(s);
+            h_plan->sp = 1;
+            h_plan->stack[0].base = 0;
+            h_plan->stack[0].cap = 1;
+            h_plan->stack[0].count[0] = 1;
+            h_plan->arena_top = (unsigned long long)R * ctx.NS;
+            h_plan->open_total = 1;
         }
+        h_plan->status = PS_DONE;
+        HIPCHK(hipMemcpyAsync(d_plan.p, h_plan, kPlanHeader + sizeof(DevSegment), hipMemcpyHostToDevice, stream));
+        int rc = push_caps();
+        if (rc != STCSP_OK) return rc;
         HIPCHK(hipStreamSynchronize(stream));
         begun = true;
         t_begin = std::chrono::steady_clock::now();
@@ -1438,6 +1693,8 @@ struct stcsp_engine {
     int read_ctl() {
         HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        for (int r = 0; r < R; r++) edge_count[r] = h_ctl[L.edge0 + r * CST];
+        n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
         uint32_t e = h_ctl[L.misc0 + MISC_ERROR * CST];
         if (e) {
             static const char *names[] = {"", "watchdog", "table spin", "edge overflow", "state overflow", "unknown set",
@@ -1448,14 +1705,11 @@ struct stcsp_engine {
     }
 
     template <int DRT>
-    void launch_expand(const ExpandArgs &a, int maxtake) {
-        const int slots = R * maxtake;
-        // enough workgroups to fill the chip a few times over; wavefronts grid-stride over the slots
-        const int blocks = std::min((slots + 3) / 4, max_blocks);
+    void launch_expand() {
         if (img_in_lds)
-            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(blocks), dim3(256), lds_bytes, stream, ctx, a, slots);
+            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, ctx);
         else
-            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(blocks), dim3(256), lds_bytes, stream, ctx, a, slots);
+            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, ctx);
     }
 
     int service_misses() {
@@ -1475,74 +1729,65 @@ struct stcsp_engine {
         return upload_program();
     }
 
-    // one launch round on the top segment: expand a chunk; unsharded engines commit right away
-    int step(bool commit_local) {
-        Segment &S = stack.back();
-        ExpandArgs a{};
-        int maxtake = 0;
-        long long taken = 0;
-        for (int r = 0; r < R; r++) {
-            a.count[r] = S.count[r];
-            a.take[r] = std::min(S.count[r], chunk_r);
-            maxtake = std::max(maxtake, a.take[r]);
-            taken += a.take[r];
-        }
-        int rc = ensure_capacity(taken, maxtake);
+    // Enqueue bursts of rounds until the device plan stops: done, outbox full (sharded), or
+    // truncated by a budget. Pool growth and constraint-set translation are served in between.
+    int run_rounds() {
+        int rc = replan();
         if (rc != STCSP_OK) return rc;
-        Segment T{};
-        T.base = arena_top;
-        T.cap = (uint32_t)(3 * maxtake);
-        rc = ensure_arena((size_t)R * T.cap * ctx.NS);
-        if (rc != STCSP_OK) return rc;
-        // zero the out cursors (and, unsharded, the outbox cursors): contiguous at the start of ctl
-        size_t zero_words = commit_local ? (size_t)L.edge0 : (size_t)L.cand0;
-        HIPCHK(hipMemsetAsync(d_ctl.p, 0, zero_words * sizeof(uint32_t), stream));
-        a.in_base = d_arena.p + S.base;
-        a.in_cap = S.cap;
-        a.out_base = d_arena.p + T.base;
-        a.out_cap = T.cap;
-        a.cand_base = d_cand.p;
-        a.cand_cap = cand_cap;
         const bool prof = opt.flags & STCSP_F_PROFILE;
-        if (prof) {
-            if (ev_used == ev_pool.size()) {
-                hipEvent_t e0, e1;
-                HIPCHK(hipEventCreate(&e0));
-                HIPCHK(hipEventCreate(&e1));
-                ev_pool.emplace_back(e0, e1);
+        for (;;) {
+            for (int k = 0; k < burst; k++) {
+                if (prof) {
+                    if (ev_used == ev_pool.size()) {
+                        hipEvent_t e0, e1;
+                        HIPCHK(hipEventCreate(&e0));
+                        HIPCHK(hipEventCreate(&e1));
+                        ev_pool.emplace_back(e0, e1);
+                    }
+                    HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+                }
+                switch (DR) {
+                    case 1: launch_expand<1>(); break;
+                    case 2: launch_expand<2>(); break;
+                    default: launch_expand<4>(); break;
+                }
+                HIPCHK(hipGetLastError());
+                if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
             }
-            HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+            rc = read_plan();
+            if (rc != STCSP_OK) return rc;
+            switch (h_plan->status) {
+                case PS_RUN: break;
+                case PS_DONE:
+                case PS_OUTBOX_FULL: return STCSP_OK;
+                case PS_NEED_ARENA: {
+                    size_t need = (size_t)h_plan->arena_top + (size_t)R * 3 * chunk_r * ctx.NS;
+                    if ((rc = grow_arena(need)) || (rc = push_caps()) || (rc = replan())) return rc;
+                    break;
+                }
+                case PS_NEED_EDGES:
+                    if ((rc = grow_edges()) || (rc = push_caps()) || (rc = replan())) return rc;
+                    break;
+                case PS_NEED_STATES:
+                    if ((rc = grow_states()) || (rc = push_caps()) || (rc = replan())) return rc;
+                    break;
+                case PS_NEED_TABLE:
+                    if ((rc = grow_table()) || (rc = push_caps()) || (rc = replan())) return rc;
+                    break;
+                case PS_HOST:
+                    if ((rc = read_ctl())) return rc;  // reports device errors
+                    if ((rc = service_misses())) return rc;
+                    sync_ctx();
+                    if ((rc = replan())) return rc;
+                    break;
+                case PS_STACK_FULL: return fail(STCSP_E_NOMEM, "frontier segment stack deeper than %d", kMaxSegments);
+                default: return fail(STCSP_E_INTERNAL, "unknown plan status %d", h_plan->status);
+            }
+            if (over_budget()) {
+                truncated = true;
+                return STCSP_OK;
+            }
         }
-        switch (DR) {
-            case 1: launch_expand<1>(a, maxtake); break;
-            case 2: launch_expand<2>(a, maxtake); break;
-            default: launch_expand<4>(a, maxtake); break;
-        }
-        HIPCHK(hipGetLastError());
-        if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
-        expand_launches++;
-        (void)commit_local;  // unsharded engines commit inside k_expand (fused)
-        rc = read_ctl();
-        if (rc != STCSP_OK) return rc;
-        levels++;
-        for (int r = 0; r < R; r++) {
-            S.count[r] -= a.take[r];
-            T.count[r] = (int)h_ctl[L.out0 + r * CST];
-            edge_count[r] = h_ctl[L.edge0 + r * CST];
-        }
-        n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
-        rc = service_misses();
-        if (rc != STCSP_OK) return rc;
-        if (T.total() > 0) {
-            arena_top = T.base + (size_t)R * T.cap * ctx.NS;
-            stack.push_back(T);  // (invalidates S)
-        }
-        // drop exhausted segments from the top
-        while (!stack.empty() && stack.back().total() == 0) {
-            arena_top = stack.back().base;
-            stack.pop_back();
-        }
-        return STCSP_OK;
     }
 
     bool over_budget() {
@@ -1564,14 +1809,8 @@ struct stcsp_engine {
     int solve_unsharded() {
         int rc = begin();
         if (rc != STCSP_OK) return rc;
-        while (!stack.empty()) {
-            if (over_budget()) {
-                truncated = true;
-                break;
-            }
-            rc = step(true);
-            if (rc != STCSP_OK) return rc;
-        }
+        rc = run_rounds();
+        if (rc != STCSP_OK) return rc;
         return finish();
     }
 
@@ -1591,6 +1830,13 @@ struct stcsp_engine {
         ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
         ctr.sweeps = (int64_t)tot[ST_SWEEPS];
         ctr.skipped_revisions = (int64_t)tot[ST_SKIPPED];
+#ifdef STCSP_PHASES
+        if (tot[ST_NODES])
+            fprintf(stderr, "[phases] cycles/node: load %.0f sweep %.0f wave %.0f classify+emit %.0f commit %.0f total %.0f (nodes %llu)\n",
+                    (double)tot[ST_CYC_LOAD] / tot[ST_NODES], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES], (double)tot[ST_CYC_WAVE] / tot[ST_NODES],
+                    (double)tot[ST_CYC_CLASSIFY] / tot[ST_NODES], (double)tot[ST_CYC_COMMIT] / tot[ST_NODES],
+                    (double)tot[ST_CYC_TOTAL] / tot[ST_NODES], (unsigned long long)tot[ST_NODES]);
+#endif
         ctr.levels = levels;
         ctr.seconds_search = finished ? seconds_search : elapsed();
         ctr.seconds_expand_kernel = seconds_expand_kernel;
@@ -1601,38 +1847,27 @@ struct stcsp_engine {
         HIPCHK(hipStreamSynchronize(stream));
         seconds_search = elapsed();
         finished = true;
+        // only launches that actually ran a round count (a burst may run past the end)
+        expand_launches = levels;
         for (size_t i = 0; i < ev_used; i++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
             seconds_expand_kernel += ms * 1e-3;
         }
         ev_used = 0;
+        int rc = read_ctl();
+        if (rc != STCSP_OK) return rc;
         return read_counters(snap);
     }
 
     // ---- sharded stepping
-    long long open_nodes() const {
-        long long t = 0;
-        for (auto &s : stack) t += s.total();
-        return t;
-    }
     int expand_local(int64_t *left) {
         if (!begun) return fail(STCSP_E_STATE, "expand_local before begin");
-        int rc;
-        while (!stack.empty()) {
-            // stop while every outbox bucket still has room for one more launch
-            uint32_t max_bucket = 0;
-            for (int o = 0; o < opt.world; o++)
-                for (int r = 0; r < R; r++) max_bucket = std::max(max_bucket, h_ctl[L.cand0 + (o * R + r) * CST]);
-            if ((long long)max_bucket + chunk_r > (long long)cand_cap) break;
-            if (over_budget()) {
-                truncated = true;
-                break;
-            }
-            rc = step(false);
-            if (rc != STCSP_OK) return rc;
-        }
-        if (left) *left = truncated ? 0 : open_nodes();
+        int rc = run_rounds();
+        if (rc != STCSP_OK) return rc;
+        rc = read_ctl();  // outbox cursors for outbox()
+        if (rc != STCSP_OK) return rc;
+        if (left) *left = truncated ? 0 : (int64_t)h_plan->open_total;
         return STCSP_OK;
     }
     int outbox(int peer, void **ptr, int64_t *count) {
@@ -1661,20 +1896,28 @@ struct stcsp_engine {
             HIPCHK(hipStreamSynchronize(stream));
             return STCSP_OK;
         }
-        int rc = ensure_capacity(count, (count + R - 1) / R + 1);
+        // room for `count` more edges / states and for the segment of new nodes
+        int rc = read_ctl();
         if (rc != STCSP_OK) return rc;
-        Segment T{};
-        T.base = arena_top;
-        T.cap = (uint32_t)((count + R - 1) / R + 1);
-        rc = ensure_arena((size_t)R * T.cap * ctx.NS);
+        rc = read_plan();
         if (rc != STCSP_OK) return rc;
-        HIPCHK(hipMemsetAsync(d_ctl.p, 0, (size_t)L.cand0 * sizeof(uint32_t), stream));
+        const long long per_region = (count + R - 1) / R + 1;
+        uint32_t max_edges = 0;
+        for (int r = 0; r < R; r++) max_edges = std::max(max_edges, edge_count[r]);
+        while ((long long)max_edges + per_region > (long long)ctx.edge_cap)
+            if ((rc = alloc_edges(ctx.edge_cap * 2))) return rc;
+        while ((long long)n_states + count > (long long)ctx.state_cap)
+            if ((rc = alloc_states(ctx.state_cap * 2))) return rc;
+        while (((long long)n_states + count) * 2 > (long long)ctx.slot_mask + 1)
+            if ((rc = grow_table())) return rc;
+        const unsigned cap = (unsigned)per_region;
+        if ((size_t)h_plan->arena_top + (size_t)R * cap * ctx.NS > d_arena.n)
+            if ((rc = grow_arena((size_t)h_plan->arena_top + (size_t)R * cap * ctx.NS))) return rc;
+        if ((rc = push_caps())) return rc;
+        hipLaunchKernelGGL(k_open_segment, dim3(1), dim3(64), 0, stream, ctx, cap);
         CommitArgs ca{};
         ca.cand_base = (const uint32_t *)records;
-        ca.regions = 0;
         ca.total = count;
-        ca.out_base = d_arena.p + T.base;
-        ca.out_cap = T.cap;
         {
             dim3 grid((unsigned)((count + 3) / 4)), block(256);
             switch (DR) {
@@ -1683,19 +1926,11 @@ struct stcsp_engine {
                 default: hipLaunchKernelGGL((k_commit<4>), grid, block, 0, stream, ctx, ca); break;
             }
         }
+        hipLaunchKernelGGL(k_close_segment, dim3(1), dim3(64), 0, stream, ctx);
         HIPCHK(hipGetLastError());
         rc = read_ctl();
         if (rc != STCSP_OK) return rc;
-        for (int r = 0; r < R; r++) {
-            T.count[r] = (int)h_ctl[L.out0 + r * CST];
-            edge_count[r] = h_ctl[L.edge0 + r * CST];
-        }
-        n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
-        if (T.total() > 0) {
-            arena_top = T.base + (size_t)R * T.cap * ctx.NS;
-            stack.push_back(T);
-        }
-        return STCSP_OK;
+        return read_plan();
     }
 
     int export_result(stcsp_result *res) {
