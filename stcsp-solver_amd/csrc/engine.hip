@@ -332,7 +332,7 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
 template <int DR, bool L>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
-                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, WaveStats &ws, uint32_t *ctl_misc) {
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc) {
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
@@ -515,6 +515,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         if (newD != Dj) {
             const int vj = (int)rdlane((uint32_t)var, j);
             dom.set(p * c.N + vj, newD, lane);
+            if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
             if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
         }
     }
@@ -617,23 +618,27 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     }
     bool consistent = true;
     unsigned guard = 0;
+    // LDS copy of the block (AND-accumulator of the sweeps); kept equal to `dom` between sweeps.
+    // Only this wavefront touches it and a wavefront's LDS operations execute in order, so
+    // wavefront-scope fences (compiler ordering only) are enough.
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.NK) ldom[idx] = (int)dom.r[q];
+    }
     while (consistent) {
         if (__ballot((dirtyw & smallmask) != 0)) {
             const unsigned long long t_sw = PHASE_NOW();
             // ---- lane-parallel sweep over the dirty small items
-#pragma unroll
-            for (int q = 0; q < DR; q++) {
-                int idx = q * 64 + lane;
-                if (idx < c.NK) ldom[idx] = (int)dom.r[q];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool lfail = false;
             ws.sweeps++;
             const int npass = (S.nsmall + 63) >> 6;
             for (int t = 0; t < npass; t++) {
                 const int item = t * 64 + lane;
-                uint32_t dw = (uint32_t)__shfl((int)dirtyw, (item >> 5) & 63, 64);
+                const uint32_t dw0 = rdlane(dirtyw, (2 * t) & 63), dw1 = rdlane(dirtyw, (2 * t + 1) & 63);
+                const uint32_t dw = lane < 32 ? dw0 : dw1;
                 const bool isd = item < S.nsmall && ((dw >> (item & 31)) & 1u);
                 unsigned long long dmask = __ballot(isd);
                 if (!dmask) continue;
@@ -700,7 +705,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
                 }
             }
             dirtyw &= ~smallmask;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (__ballot(lfail)) {
                 consistent = false;
@@ -739,7 +744,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         const int ipoint = P.u(ibase + 1), icon = P.u(ibase + 2);
         ConDesc C;
         load_con<L>(c, P, icon, C);
-        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ws, misc);
+        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc);
         ws.cyc_wave += PHASE_NOW() - t_wv;
         if (++guard > (1u << 20)) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
@@ -1132,6 +1137,9 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
     uint32_t pos = (uint32_t)h & c.slot_mask;
     uint32_t idx = 0;
     bool is_new = false;
+    // the edge slot is needed whatever the lookup finds: request it now, use it after the probe
+    uint32_t e = 0;
+    if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + ro * CST], 1u);
     for (unsigned probes = 0;; probes++) {
         unsigned long long sv = 0;
         bool claimed = false;
@@ -1191,8 +1199,6 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
         }
     }
     // edge record: src (global id), dst (local index), label = time-0 value of every variable
-    uint32_t e = 0;
-    if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + ro * CST], 1u);
     e = rflu(e);
     if (e >= c.edge_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_EDGE_OVERFLOW);
@@ -1511,18 +1517,20 @@ struct stcsp_engine {
         ctx.miss = d_miss.p;
         HIPCHK(d_stats.alloc(kStatSlots * kStatWords));
         ctx.stats = d_stats.p;
-        rc = alloc_table(1u << 20);
+        // STCSP_SMALL_POOLS=1 (tests): start with tiny pools so that every growth path is exercised
+        const bool small_pools = getenv("STCSP_SMALL_POOLS") && atoi(getenv("STCSP_SMALL_POOLS")) != 0;
+        rc = alloc_table(small_pools ? 64u : 1u << 20);
         if (rc != STCSP_OK) return rc;
-        rc = alloc_states(1u << 19);
+        rc = alloc_states(small_pools ? 16u : 1u << 19);
         if (rc != STCSP_OK) return rc;
-        rc = alloc_edges(1u << 15);
+        rc = alloc_edges(small_pools ? 8u : 1u << 15);
         if (rc != STCSP_OK) return rc;
         // outbox: [owner][region] x cand_cap records. Unsharded: emptied after every launch.
         cand_cap = (uint32_t)(opt.world > 1 ? std::max(4 * chunk_r, 4096) : chunk_r);
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (opt.world > 1) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
-        HIPCHK(d_arena.alloc((size_t)8 * R * chunk_r * ctx.NS));
+        HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : (size_t)8 * R * chunk_r * ctx.NS));
         HIPCHK(d_plan.alloc(1));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));

@@ -140,3 +140,16 @@ def test_engine_synthetic_64x32_timebox(stcsp):
     assert r.truncated == 1
     assert r.counters.search_nodes > 1_000_000
     assert r.counters.fails > 0
+
+
+def test_engine_pool_growth_paths(stcsp, golden, monkeypatch):
+    """Start with tiny device pools (STCSP_SMALL_POOLS): the frontier arena, edge log, state pool
+    and hash table all have to grow (realloc / rehash between launch bursts) several times."""
+    monkeypatch.setenv("STCSP_SMALL_POOLS", "1")
+    for name in ["juggling_b4_f5_nosym", "digitinvader3", "partialorder_11"]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m)
+        r = e.solve()
+        a, _ = finish(e, r)
+        assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
+        assert r.n_states == golden[name]["node"] or golden[name]["fail"] > 0
