@@ -182,7 +182,7 @@ def hip_lib() -> C.CDLL:
     """The HIP engine. Fails loudly when the extension is missing or cannot be loaded."""
     global _hip
     if _hip is None:
-        path = CSRC / "libstcsp_hip.so"
+        path = Path(os.environ.get("STCSP_HIP_LIB", CSRC / "libstcsp_hip.so"))  # override: tuning builds
         if not path.exists():
             raise RuntimeError(f"HIP engine library {path} is missing -- build it (make -C {CSRC}); "
                                "there is no CPU fallback")

@@ -1072,8 +1072,14 @@ __global__ void k_close_segment(Ctx c) {
 // Each workgroup first stages the program image into LDS (when L), then its four wavefronts
 // loop over the round's node slots with a grid stride; the last workgroup to finish accounts
 // the round and plans the next one.
+#ifndef STCSP_EXPAND_WAVES
+#define STCSP_EXPAND_WAVES 1
+#endif
+// Ctx is read through a pointer (scalar loads on demand): passing it by value kept ~130 SGPRs
+// live/spilled and cost a wavefront of occupancy per SIMD.
 template <int DR, bool L>
-__global__ __launch_bounds__(256) void k_expand(Ctx c) {
+__global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *__restrict__ cp) {
+    const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -1351,7 +1357,7 @@ struct stcsp_engine {
     CtlLayout L{1};
     size_t lds_bytes = 0;
     int chunk_r = 0;  // max nodes taken per region per launch
-    int max_blocks = 256 * 8;  // k_expand grid cap (workgroups)
+    int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
     DevBuf<int> d_var_lb, d_arr_off, d_arr_data, d_sig_vars, d_until_y, d_scope, d_code, d_firstvars, d_transvals, d_miss;
     DevBuf<uint32_t> d_var_init, d_varcons, d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack;
@@ -1365,6 +1371,8 @@ struct stcsp_engine {
     int *h_miss = nullptr;      // pinned
     uint32_t cand_cap = 0;
     DevBuf<Plan> d_plan;
+    DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
+    Ctx *h_ctx = nullptr;    // pinned staging copy
     Plan *h_plan = nullptr;  // pinned mirror of the plan header (everything before the stack)
     int burst = 8;           // rounds enqueued per host synchronisation
     std::vector<uint32_t> edge_count = std::vector<uint32_t>(R, 0);
@@ -1394,6 +1402,7 @@ struct stcsp_engine {
         }
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_plan) (void)hipHostFree(h_plan);
+        if (h_ctx) (void)hipHostFree(h_ctx);
         if (h_miss) (void)hipHostFree(h_miss);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1462,6 +1471,24 @@ struct stcsp_engine {
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
         if (const char *ev = getenv("STCSP_IMG_LDS")) img_in_lds = img_in_lds && atoi(ev) != 0;  // tuning switch
         lds_bytes = scratch + (img_in_lds ? (size_t)o.words * 4 : 0);
+        // Grid = exactly the workgroups that are resident at once: wavefronts take node slots with
+        // a static grid stride, so a workgroup that has to wait for a free CU slot would start its
+        // share only when another one has finished all of its own (a 2x tail).
+        {
+            int per_cu = 0;
+            hipError_t e;
+            const void *fn;
+            switch (DR) {
+                case 1: fn = img_in_lds ? (const void *)k_expand<1, true> : (const void *)k_expand<1, false>; break;
+                case 2: fn = img_in_lds ? (const void *)k_expand<2, true> : (const void *)k_expand<2, false>; break;
+                default: fn = img_in_lds ? (const void *)k_expand<4, true> : (const void *)k_expand<4, false>; break;
+            }
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
+            hipDeviceProp_t prop;
+            if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
+                max_blocks = per_cu * prop.multiProcessorCount;
+            if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
+        }
         return STCSP_OK;
     }
 
@@ -1532,9 +1559,10 @@ struct stcsp_engine {
         // arena of node segments (grown on demand)
         HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : (size_t)8 * R * chunk_r * ctx.NS));
         HIPCHK(d_plan.alloc(1));
+        HIPCHK(d_ctx.alloc(1));
+        HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
-        if (const char *ev = getenv("STCSP_BLOCKS")) max_blocks = std::max(1, atoi(ev));
         sync_ctx();
         return STCSP_OK;
     }
@@ -1715,9 +1743,9 @@ struct stcsp_engine {
     template <int DRT>
     void launch_expand() {
         if (img_in_lds)
-            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, ctx);
+            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
         else
-            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, ctx);
+            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
     }
 
     int service_misses() {
@@ -1744,6 +1772,12 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         const bool prof = opt.flags & STCSP_F_PROFILE;
         for (;;) {
+            sync_ctx();
+            if (memcmp(h_ctx, &ctx, sizeof(Ctx)) != 0) {  // pools / program moved: refresh the device copy
+                HIPCHK(hipStreamSynchronize(stream));      // (the staging copy may still be in flight)
+                memcpy(h_ctx, &ctx, sizeof(Ctx));
+                HIPCHK(hipMemcpyAsync(d_ctx.p, h_ctx, sizeof(Ctx), hipMemcpyHostToDevice, stream));
+            }
             for (int k = 0; k < burst; k++) {
                 if (prof) {
                     if (ev_used == ev_pool.size()) {
