@@ -1331,17 +1331,6 @@ struct DevBuf {
     }
 };
 
-struct Segment {
-    size_t base;   // word offset into the arena
-    uint32_t cap;  // node slots per region
-    int count[R];
-    long long total() const {
-        long long t = 0;
-        for (int r = 0; r < R; r++) t += count[r];
-        return t;
-    }
-};
-
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -1359,13 +1348,9 @@ struct stcsp_engine {
     int chunk_r = 0;  // max nodes taken per region per launch
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
-    DevBuf<int> d_var_lb, d_arr_off, d_arr_data, d_sig_vars, d_until_y, d_scope, d_code, d_firstvars, d_transvals, d_miss;
-    DevBuf<uint32_t> d_var_init, d_varcons, d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack;
-    DevBuf<uint32_t> d_img;
+    DevBuf<int> d_arr_data, d_code, d_miss;
+    DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
     bool img_in_lds = false;
-    DevBuf<SetDesc> d_sets;
-    DevBuf<ConDesc> d_cons;
-    DevBuf<TransDesc> d_trans;
     DevBuf<unsigned long long> d_slots, d_stats;
     uint32_t *h_ctl = nullptr;  // pinned
     int *h_miss = nullptr;      // pinned
@@ -1795,6 +1780,7 @@ struct stcsp_engine {
                 }
                 HIPCHK(hipGetLastError());
                 if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
+                expand_launches++;
             }
             rc = read_plan();
             if (rc != STCSP_OK) return rc;
@@ -1889,8 +1875,8 @@ struct stcsp_engine {
         HIPCHK(hipStreamSynchronize(stream));
         seconds_search = elapsed();
         finished = true;
-        // only launches that actually ran a round count (a burst may run past the end)
-        expand_launches = levels;
+        // every enqueued launch counts (a burst may run a few no-op launches past the end), so that
+        // the average agrees with rocprofv3's per-kernel average
         for (size_t i = 0; i < ev_used; i++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
