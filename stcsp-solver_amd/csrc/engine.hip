@@ -573,6 +573,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
     const unsigned long long t_start = PHASE_NOW();
+    (void)t_start;
 
     const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
     Dom<DR> dom;
@@ -601,6 +602,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
     WaveStats ws;
     const unsigned long long t_loaded = PHASE_NOW();
+    (void)t_loaded;
     int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
     uint32_t dirtyw = 0;
     if (lane < S.iw) {
@@ -765,6 +767,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
 #endif
     }
     const unsigned long long t_prop = PHASE_NOW();
+    (void)t_prop;
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
         return;
@@ -895,6 +898,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     if (c.world == 1) {
         // unsharded: commit right here, the leaf's data never leaves the registers
         const unsigned long long t_cm = PHASE_NOW();
+        (void)t_cm;
         commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, kw, h, h0, h1, next_set, next_tag, new_expire, evals, nblk, gw);
 #ifdef STCSP_PHASES
         if (lane == 0) {
