@@ -553,44 +553,52 @@ __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t
     }
 }
 
+enum Outcome : int { OC_FAIL = 0, OC_BRANCH, OC_MISS, OC_LEAF };
+struct NodeHdr {
+    uint32_t h0, h1;  // src state (global id)
+    int set;          // constraint set index
+    uint32_t seed;    // dirty seed (see k_expand)
+    uint32_t expire;  // until-expire bits
+};
+struct BranchOut {
+    int bvar;
+    uint32_t D, lowmask;  // children: D & lowmask, D & ~lowmask at word (0, bvar)
+};
 template <int DR>
-__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity, uint32_t kw,
-                            unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
-                            const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot);
+struct LeafOut {
+    uint32_t kw;            // lane j: key word j = [next set tag, signature...]
+    unsigned long long h;   // key hash
+    int next_set, owner;
+    uint32_t next_tag, new_expire;
+    uint32_t evals[DR];     // edge label (Edge::values), lane-striped
+    uint32_t nblk[DR];      // time-advanced block, lane-striped
+};
+struct CommitOut {
+    uint32_t idx;  // local state index
+    bool is_new, ok;
+    int set;
+};
+template <int DR>
+__device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, unsigned long long h, uint32_t s0, uint32_t s1,
+                                  int set, uint32_t tag, const uint32_t (&vals)[DR], int stat_slot);
+template <int DR>
+__device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
+                                const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]);
 
-// ------------------------------------------------------------------ k_expand
-// expand ONE open node (slot `gw` of this launch) with one wavefront
+// ------------------------------------------------------------------ one search node
+// Propagate the block in `dom` to its fixpoint under the node's constraint set and classify the
+// node like solverSolveRe does: failed / branch / leaf (or "miss": a leaf whose constraint-set
+// translation the host has not provided yet). Outputs stay in registers; the callers (the
+// round-based k_expand and the persistent k_persist) decide where children and leaves go.
 template <int DR, bool L>
-__device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
-    const int r = gw % R, i = gw / R;
-    const int take_r = kload(c.plan, (int)(offsetof(Plan, take) / 4) + r);
-    if (i >= take_r) return;
-    const int count_r = kload(c.plan, (int)(offsetof(Plan, count) / 4) + r);
-    // outputs go to another cursor shard than the input's, or a subtree would stay in the region
-    // of its root forever; for every i exactly one input region maps to each output region, so
-    // an output region receives from at most max(take) wavefronts
-    const int ro = (i + r) % R;
+__device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, Dom<DR> &dom,
+                            const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
     const unsigned long long t_start = PHASE_NOW();
     (void)t_start;
-
-    const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
-    Dom<DR> dom;
-#pragma unroll
-    for (int q = 0; q < DR; q++) {
-        int idx = q * 64 + lane;
-        dom.r[q] = idx < c.NK ? node[4 + idx] : 0u;
-    }
-    const uint32_t h0 = rflu(node[0]), h1 = rflu(node[1]);
-    // header word 2: constraint set (low 16 bits) | dirty seed (high 16 bits): 0 = revise every
-    // constraint (fresh state / root), 0xffff = nothing to revise (re-queued fixpoint), else
-    // 1 + the variable whose domain the parent just bisected -- the parent block was at its
-    // fixpoint, so only that variable's constraints can have lost supports
-    const uint32_t w2 = rflu(node[2]);
-    const int set = (int)(w2 & 0xffffu);
-    const uint32_t seed = w2 >> 16;
-    const uint32_t expire = rflu(node[3]);
+    const int set = hd.set;
+    const uint32_t seed = hd.seed, expire = hd.expire;
     SetDesc S;
     load_set<L>(c, P, set, S);
 
@@ -770,7 +778,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     (void)t_prop;
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
-        return;
+        return OC_FAIL;
     }
 
     // ---- classify (solverGetFirstUnboundVar, src/solver.cpp:41-53): first variable, in queue
@@ -782,33 +790,15 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         unsigned long long m = __ballot(idx < c.N && __popc(dom.r[q]) > 1);
         if (bvar < 0 && m) bvar = q * 64 + __ffsll((long long)m) - 1;
     }
-    uint32_t *out_region = a.out_base + (size_t)ro * a.out_cap * c.NS;
     if (bvar >= 0) {
         // bisect [lb,ub] of the branching variable (variableSplitLower/Upper, variable.cpp:52-67)
-        uint32_t D = dom.get(bvar);
-        int lo = __ffs((int)D) - 1, hi = 31 - __clz((int)D);
-        int mid = lo + (hi - lo) / 2;
-        uint32_t lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 2u);
-        pos = rflu(pos);
-        if (pos + 2 > a.out_cap) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
-            return;
-        }
-        Dom<DR> child = dom;
-        child.set(bvar, D & lowmask, lane);
-        const uint32_t cw2 = (uint32_t)set | ((uint32_t)(bvar + 1) << 16);
-        store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, cw2, expire, child, lane);
-        child.set(bvar, D & ~lowmask, lane);
-        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, h0, h1, cw2, expire, child, lane);
-#ifdef STCSP_PHASES
-        if (lane == 0) {
-            add_stats(c, gw, ST_CYC_CLASSIFY, PHASE_NOW() - t_prop);
-            add_stats(c, gw, ST_CYC_TOTAL, PHASE_NOW() - t_start);
-        }
-#endif
-        return;
+        const uint32_t D = dom.get(bvar);
+        const int lo_ = __ffs((int)D) - 1, hi_ = 31 - __clz((int)D);
+        const int mid = lo_ + (hi_ - lo_) / 2;
+        bo.bvar = bvar;
+        bo.D = D;
+        bo.lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
+        return OC_BRANCH;
     }
 
     // ---- leaf: every variable has a single time-0 value (solveralgorithm.cpp:739-910)
@@ -841,16 +831,8 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
                 }
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
-            pos = rflu(pos);
-            if (pos + 1 > a.out_cap) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
-                return;
-            }
-            store_node<DR>(out_region + (size_t)pos * c.NS, c, h0, h1, (uint32_t)set | 0xffff0000u, expire, dom, lane);
             if (lane == 0) add_stats(c, gw, ST_REQUEUE, 1);
-            return;
+            return OC_MISS;
         }
     }
     const uint32_t next_tag = (uint32_t)P.u(c.o.sets + next_set * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
@@ -878,56 +860,122 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     unsigned long long h = kHashSeed;
     for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
     h = mix_final(h);
-    const int owner = (int)((h >> 40) % (unsigned)c.world);
+    lo.kw = kw;
+    lo.h = h;
+    lo.next_set = next_set;
+    lo.next_tag = next_tag;
+    lo.new_expire = new_expire;
+    lo.owner = (int)((h >> 40) % (unsigned)c.world);
     // edge label (Edge::values) and the time-advanced block (variableAdvanceOneTimeStep,
     // variable.cpp:94-108: point p <- point p+1, last point <- [lb,ub]), lane-striped
-    uint32_t evals[DR], nblk[DR];
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int idx = q * 64 + lane;
-        evals[q] = idx < c.N ? (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1) : 0u;
+        lo.evals[q] = idx < c.N ? (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1) : 0u;
         uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
         uint32_t nb = 0;
         if (idx < c.NK) {
             int p = idx / c.N, v = idx - p * c.N;
             nb = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
         }
-        nblk[q] = nb;
+        lo.nblk[q] = nb;
     }
     if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
-    if (c.world == 1) {
-        // unsharded: commit right here, the leaf's data never leaves the registers
-        const unsigned long long t_cm = PHASE_NOW();
-        (void)t_cm;
-        commit_core<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, kw, h, h0, h1, next_set, next_tag, new_expire, evals, nblk, gw);
-#ifdef STCSP_PHASES
-        if (lane == 0) {
-            add_stats(c, gw, ST_CYC_CLASSIFY, t_cm - t_prop);
-            add_stats(c, gw, ST_CYC_COMMIT, PHASE_NOW() - t_cm);
-            add_stats(c, gw, ST_CYC_TOTAL, PHASE_NOW() - t_start);
+    return OC_LEAF;
+}
+
+// ------------------------------------------------------------------ k_expand (round-based)
+// expand ONE open node (slot `gw` of this round) with one wavefront
+template <int DR, bool L>
+__device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
+    const int r = gw % R, i = gw / R;
+    const int take_r = kload(c.plan, (int)(offsetof(Plan, take) / 4) + r);
+    if (i >= take_r) return;
+    const int count_r = kload(c.plan, (int)(offsetof(Plan, count) / 4) + r);
+    // outputs go to another cursor shard than the input's, or a subtree would stay in the region
+    // of its root forever; for every i exactly one input region maps to each output region, so
+    // an output region receives from at most max(take) wavefronts
+    const int ro = (i + r) % R;
+    const CtlLayout L_(c.world);
+    uint32_t *misc = c.ctl + L_.misc0;
+    const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
+    Dom<DR> dom;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        dom.r[q] = idx < c.NK ? node[4 + idx] : 0u;
+    }
+    // header word 2: constraint set (low 16 bits) | dirty seed (high 16 bits): 0 = revise every
+    // item (fresh state / root), 0xffff = nothing to revise (re-queued fixpoint), else 1 + the
+    // variable whose time-0 domain the parent just bisected -- the parent block was at its
+    // fixpoint, so only items reading that word can have lost supports
+    NodeHdr hd;
+    hd.h0 = rflu(node[0]);
+    hd.h1 = rflu(node[1]);
+    const uint32_t w2 = rflu(node[2]);
+    hd.set = (int)(w2 & 0xffffu);
+    hd.seed = w2 >> 16;
+    hd.expire = rflu(node[3]);
+    BranchOut bo;
+    LeafOut<DR> lo;
+    const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+    if (oc == OC_FAIL) return;
+    uint32_t *out_region = a.out_base + (size_t)ro * a.out_cap * c.NS;
+    if (oc == OC_BRANCH) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 2u);
+        pos = rflu(pos);
+        if (pos + 2 > a.out_cap) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+            return;
         }
-#endif
+        Dom<DR> child = dom;
+        child.set(bo.bvar, bo.D & bo.lowmask, lane);
+        const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
+        store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
+        child.set(bo.bvar, bo.D & ~bo.lowmask, lane);
+        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
         return;
     }
-    // (4) sharded: candidate record for the owner: header, signature, edge label, block
+    if (oc == OC_MISS) {  // park the (propagated) node again until the host has translated the set
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
+        pos = rflu(pos);
+        if (pos + 1 > a.out_cap) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+            return;
+        }
+        store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
+        return;
+    }
+    // leaf
+    if (c.world == 1) {
+        // unsharded: commit right here, the leaf's data never leaves the registers
+        CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, gw);
+        if (co.ok && co.is_new) emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk);
+        return;
+    }
+    // sharded: candidate record for the owner: header, signature, edge label, block
     uint32_t pos = 0;
-    if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (owner * R + ro) * CST], 1u);
+    if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
     pos = rflu(pos);
     if (pos + 1 > a.cand_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
         return;
     }
-    uint32_t *rec = a.cand_base + ((size_t)(owner * R + ro) * a.cand_cap + pos) * c.CS;
+    uint32_t *rec = a.cand_base + ((size_t)(lo.owner * R + ro) * a.cand_cap + pos) * c.CS;
     if (lane < 6)
-        rec[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? next_tag : (lane == 3 ? new_expire : (lane == 4 ? (uint32_t)h : (uint32_t)(h >> 32)))));
-    if (lane >= 1 && lane <= c.sig_len) rec[kCandHdr + lane - 1] = kw;
+        rec[lane] = lane == 0 ? hd.h0
+                  : (lane == 1 ? hd.h1
+                  : (lane == 2 ? lo.next_tag : (lane == 3 ? lo.new_expire : (lane == 4 ? (uint32_t)lo.h : (uint32_t)(lo.h >> 32)))));
+    if (lane >= 1 && lane <= c.sig_len) rec[kCandHdr + lane - 1] = lo.kw;
     uint32_t *vals = rec + kCandHdr + c.sig_len;
     uint32_t *blk = vals + c.N;
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int idx = q * 64 + lane;
-        if (idx < c.N) vals[idx] = evals[q];
-        if (idx < c.NK) blk[idx] = nblk[q];
+        if (idx < c.N) vals[idx] = lo.evals[q];
+        if (idx < c.NK) blk[idx] = lo.nblk[q];
     }
 }
 
@@ -1131,18 +1179,20 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
 }
 
 // ------------------------------------------------------------------ commit
-// Lookup-or-insert the state (set tag, signature) held lane-striped in `kw` (lane j = key word j),
-// append the edge record and, for a new state, open its first search node.  Used by k_expand
-// directly (unsharded: the leaf's data is still in registers) and by k_commit (sharded: the data
-// arrives as candidate records).  vals / blk are lane-striped like the domain block.
+// Lookup-or-insert the state (set tag, signature) held lane-striped in `kw` (lane j = key word j)
+// and append the edge record (label `vals`, lane-striped like the domain block).
 // Role of vertexTableGetVertex / vertexNew + vertexTableAddVertex / edgeNew + vertexAddEdge
 // (reference src/graph.cpp:14-38, 78-89, 108-123).
 template <int DR>
-__device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity, uint32_t kw,
-                            unsigned long long h, uint32_t s0, uint32_t s1, int set, uint32_t tag, uint32_t expire,
-                            const uint32_t (&vals)[DR], const uint32_t (&blk)[DR], int stat_slot) {
+__device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, unsigned long long h, uint32_t s0, uint32_t s1,
+                                  int set, uint32_t tag, const uint32_t (&vals)[DR], int stat_slot) {
     const CtlLayout L(c.world);
     uint32_t *misc = c.ctl + L.misc0;
+    CommitOut out;
+    out.idx = 0;
+    out.is_new = false;
+    out.ok = false;
+    out.set = set;
     const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
     uint32_t pos = (uint32_t)h & c.slot_mask;
     uint32_t idx = 0;
@@ -1170,7 +1220,7 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
             ni = rflu(ni);
             if (ni >= c.state_cap) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
-                return;
+                return out;
             }
             if (lane < c.KL) __hip_atomic_store(&c.state_keys[(size_t)ni * c.KL + lane], kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1190,7 +1240,7 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
                 lo = rflu((uint32_t)t);
                 if (++spins > (1u << 22)) {
                     if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_TABLE_SPIN);
-                    return;
+                    return out;
                 }
             }
             // no acquire fence: every access to a key word is an agent-scope (sc1, L1-bypassing)
@@ -1205,14 +1255,14 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
         pos = (pos + 1) & c.slot_mask;
         if (probes > c.slot_mask) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
-            return;
+            return out;
         }
     }
     // edge record: src (global id), dst (local index), label = time-0 value of every variable
     e = rflu(e);
     if (e >= c.edge_cap) {
         if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_EDGE_OVERFLOW);
-        return;
+        return out;
     }
     uint32_t *er = c.edges + ((size_t)ro * c.edge_cap + e) * c.ES;
     if (lane < 4) er[lane] = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? idx : 0u));
@@ -1221,32 +1271,44 @@ __device__ void commit_core(const Ctx &c, int lane, int ro, uint32_t *out_base, 
         int k = q * 64 + lane;
         if (k < c.N) er[4 + k] = vals[q];
     }
-    if (!is_new) return;
-    // new state: open its first search node
-    if (set < 0) {
-        for (int t = 0; t < c.nsets && set < 0; t++)
-            if ((uint32_t)kload(c.img, c.o.sets + t * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = t;
-        if (set < 0) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
-            return;
+    out.idx = idx;
+    out.is_new = is_new;
+    out.ok = true;
+    if (is_new) {
+        if (set < 0) {  // sharded: the record names the set by tag
+            for (int t = 0; t < c.nsets && set < 0; t++)
+                if ((uint32_t)kload(c.img, c.o.sets + t * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = t;
+            if (set < 0) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
+                out.ok = false;
+            }
         }
+        out.set = set;
+        if (lane == 0) add_stats(c, stat_slot, ST_NEWSTATES, 1);
     }
+    return out;
+}
+
+// new state: open its first search node in the round's output segment
+template <int DR>
+__device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
+                                const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]) {
+    const CtlLayout L(c.world);
     uint32_t np = 0;
     if (lane == 0) np = atomicAdd(&c.ctl[L.out(parity, ro)], 1u);
     np = rflu(np);
     if (np + 1 > out_cap) {
-        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+        if (lane == 0) atomicMax(&c.ctl[L.misc0 + MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
         return;
     }
     uint32_t *dst = out_base + ((size_t)ro * out_cap + np) * c.NS;
-    const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | idx;
-    if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)set : expire));
+    const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
+    if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)co.set : expire));
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int k = q * 64 + lane;
         if (k < c.NK) dst[4 + k] = blk[q];
     }
-    if (lane == 0) add_stats(c, stat_slot, ST_NEWSTATES, 1);
 }
 
 // ------------------------------------------------------------------ k_commit (sharded runs)
@@ -1272,8 +1334,8 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
         vals[q] = k < c.N ? pv[k] : 0u;
         blk[q] = k < c.NK ? pb[k] : 0u;
     }
-    commit_core<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, kw, h, s0, s1, -1, tag, expire, vals, blk,
-                    (int)(gw & 0x7fffffff));
+    CommitOut co = table_commit<DR>(c, lane, ro, kw, h, s0, s1, -1, tag, vals, (int)(gw & 0x7fffffff));
+    if (co.ok && co.is_new) emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk);
 }
 
 // gather the R regions of one owner's outbox into a contiguous array (for the all-to-all)
