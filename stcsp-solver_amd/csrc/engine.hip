@@ -54,9 +54,10 @@ namespace {
 constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
-constexpr int kStatWords = 16;
+constexpr int kStatWords = 24;
 enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
-       ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL };
+       ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
+       ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED };
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
@@ -124,7 +125,21 @@ struct Ctx {
     Plan *plan;
     uint32_t *arena;
     uint32_t *cand;  // outbox [owner][region] x cand_cap records (sharded runs)
+    // persistent mode (k_persist): shared ring of node records + per-wavefront private stacks
+    uint32_t *pq;      // control words, one per 64-byte line: see PQ_*
+    uint32_t *ring;    // qcap node records
+    uint32_t *seq;     // qcap sequence numbers (bounded MPMC queue)
+    uint32_t *pstack;  // [wavefront][pstk_cap] node records
+    uint32_t *parked;  // nodes waiting for a constraint-set translation
+    uint32_t qmask;    // qcap - 1
+    int pstk_cap, park_cap, hungry;
 };
+enum { PQ_HEAD = 0, PQ_TAIL = 16, PQ_PENDING = 32, PQ_ABORT = 48, PQ_PARKED = 64, PQ_WORDS = 80 };
+#ifndef STCSP_MAX_BACKOFF
+#define STCSP_MAX_BACKOFF 128
+#endif
+constexpr unsigned kMaxBackoff = STCSP_MAX_BACKOFF;
+enum { AB_NONE = 0, AB_QUEUE_FULL = 1, AB_PARK_FULL = 2, AB_SPIN = 3, AB_DEVICE_ERROR = 4 };
 
 struct ExpandArgs {  // per-round view, read from the device plan by every wavefront
     const uint32_t *in_base;
@@ -1178,6 +1193,308 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
     }
 }
 
+// ------------------------------------------------------------------ k_persist (experimental, opt-in)
+// STATUS: correct (parity-tested) but slower than the round-based default at full occupancy:
+// measured on partialorder_14, 64 wavefronts run at the round-based per-node cost, 5,120 take
+// ~190 ms -- the agent-scope loads of thousands of idle pollers serialise on the ring's hot cache
+// lines (~21 M operations/s whatever the back-off) and the producers' atomics queue behind them.
+// A competitive version needs sharded rings / per-CU wake-ups.
+//
+// Persistent work-queue variant of the search (unsharded runs): no rounds, no host in the loop.
+// Every wavefront runs depth-first: after a bisection it keeps the lower child in registers and
+// puts the upper child on its PRIVATE stack (its own slice of HBM); after a leaf that opened a
+// new state it continues with that state's first node. Work is shared through a bounded
+// multi-producer/multi-consumer ring (sequence-number protocol): a busy wavefront pushes a child
+// there instead of on its private stack while the ring is "hungry", idle wavefronts pop from it.
+// Termination: PQ_PENDING counts tasks (= ring items) that were pushed and are not finished yet;
+// a pusher increments it, the wavefront that popped a task decrements it once the task and all of
+// its private descendants are done; idle wavefronts leave when it is 0. A failed pop touches no
+// counter. Every spin is bounded and a global abort word ends the launch.
+__device__ __forceinline__ uint32_t aldw(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void astw(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int DR>
+__device__ __forceinline__ void ring_store(const Ctx &c, uint32_t *rec, const NodeHdr &hd, const Dom<DR> &dom, int lane) {
+    // agent-scope (write-through) stores: the record is read by another CU
+    if (lane < 4) astw(&rec[lane], lane == 0 ? hd.h0 : (lane == 1 ? hd.h1 : (lane == 2 ? ((uint32_t)hd.set | (hd.seed << 16)) : hd.expire)));
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.NK) astw(&rec[4 + idx], dom.r[q]);
+    }
+}
+template <int DR>
+__device__ __forceinline__ void ring_load(const Ctx &c, const uint32_t *rec, NodeHdr &hd, Dom<DR> &dom, int lane) {
+    uint32_t hw = lane < 4 ? aldw(&rec[lane]) : 0u;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        dom.r[q] = idx < c.NK ? aldw(&rec[4 + idx]) : 0u;
+    }
+    hd.h0 = rdlane(hw, 0);
+    hd.h1 = rdlane(hw, 1);
+    const uint32_t w2 = rdlane(hw, 2);
+    hd.set = (int)(w2 & 0xffffu);
+    hd.seed = w2 >> 16;
+    hd.expire = rdlane(hw, 3);
+}
+
+// push one node record on the shared ring. The producer takes its slot with ONE fetch-add (a
+// CAS loop here turns into an O(contenders^2) retry storm when many wavefronts share at once);
+// the sharing policy keeps the ring far from full, so the slot is normally free at once --
+// otherwise wait (bounded) for the consumer of the previous lap. false = gave up (abort set).
+template <int DR>
+__device__ bool q_push(const Ctx &c, const NodeHdr &hd, const Dom<DR> &dom, int lane) {
+    uint32_t pos = 0;
+    int ok = 1;
+    if (lane == 0) {
+        atomicAdd(&c.pq[PQ_PENDING], 1u);
+        pos = atomicAdd(&c.pq[PQ_TAIL], 1u);
+        unsigned spins = 0;
+        while (aldw(&c.seq[pos & c.qmask]) != pos) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) {
+                atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_QUEUE_FULL);
+                ok = 0;
+                break;
+            }
+        }
+    }
+    if (!rfl(ok)) return false;
+    pos = rflu(pos);
+    ring_store<DR>(c, c.ring + (size_t)(pos & c.qmask) * c.NS, hd, dom, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing lane is in this wavefront
+    if (lane == 0) astw(&c.seq[pos & c.qmask], pos + 1);
+    return true;
+}
+
+// pop one node record; false when the ring looks empty OR another consumer won the race (the
+// caller backs off; no hot retry). No counter is touched either way: the popped task stays
+// counted in PQ_PENDING until its wavefront has finished it.
+template <int DR>
+__device__ bool q_pop(const Ctx &c, NodeHdr &hd, Dom<DR> &dom, int lane) {
+    uint32_t pos = 0;
+    int got = 0;
+    if (lane == 0) {
+        pos = aldw(&c.pq[PQ_HEAD]);
+        if (aldw(&c.seq[pos & c.qmask]) == pos + 1) got = atomicCAS(&c.pq[PQ_HEAD], pos, pos + 1) == pos;
+    }
+    if (!rfl(got)) return false;
+    pos = rflu(pos);
+    ring_load<DR>(c, c.ring + (size_t)(pos & c.qmask) * c.NS, hd, dom, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) astw(&c.seq[pos & c.qmask], pos + c.qmask + 1);  // slot free for the next lap
+    return true;
+}
+
+#ifndef STCSP_PERSIST_WAVES
+#define STCSP_PERSIST_WAVES 5
+#endif
+template <int DR, bool L>
+__global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx *__restrict__ cp) {
+    const Ctx &c = *cp;
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    if (L) {
+        const uint4 *src = (const uint4 *)c.img;
+        uint4 *dst = (uint4 *)smem;
+        for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
+        __syncthreads();
+    }
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
+    int *lds_vals = smem + img_words + wib * per_wave;
+    int *lds_stk = lds_vals + kMaxLowVars * 64;
+    Img<L> P{L ? (const uint32_t *)smem : c.img};
+    const int wid = blockIdx.x * 4 + wib;
+    uint32_t *mystack = c.pstack + (size_t)wid * c.pstk_cap * c.NS;
+    const CtlLayout L_(c.world);
+    uint32_t *misc = c.ctl + L_.misc0;
+
+    int sp = 0;            // private stack depth
+    bool have = false;     // a node is in registers
+    bool counted = false;  // this wavefront is counted in PQ_ACTIVE
+    Dom<DR> dom;
+    NodeHdr hd{};
+    unsigned long long dbg_idle = 0, dbg_busy = 0, dbg_t = __builtin_amdgcn_s_memtime();
+    unsigned dbg_push = 0, dbg_pop = 0, dbg_polls = 0, dbg_ppop = 0;
+    unsigned polls = 0, nodes_done = 0;
+    // pollers are staggered: each wavefront starts at its own point of the back-off range
+    unsigned backoff = 1u + ((unsigned)wid * 2654435761u >> 26);  // 1..64 us
+    uint32_t last_tail = 0;
+    bool empty_seen = false;
+    for (;;) {
+        if (!have) {
+            if (sp > 0) {  // next sibling from the private stack (own stores: plain accesses)
+                sp--;
+                dbg_ppop++;
+                const uint32_t *rec = mystack + (size_t)sp * c.NS;
+                uint32_t hw = lane < 4 ? rec[lane] : 0u;
+#pragma unroll
+                for (int q = 0; q < DR; q++) {
+                    int idx = q * 64 + lane;
+                    dom.r[q] = idx < c.NK ? rec[4 + idx] : 0u;
+                }
+                hd.h0 = rdlane(hw, 0);
+                hd.h1 = rdlane(hw, 1);
+                const uint32_t w2 = rdlane(hw, 2);
+                hd.set = (int)(w2 & 0xffffu);
+                hd.seed = w2 >> 16;
+                hd.expire = rdlane(hw, 3);
+                have = true;
+            } else {
+                if (counted) {  // the task I popped (and everything below it that I kept) is done
+                    if (lane == 0) atomicSub(&c.pq[PQ_PENDING], 1u);
+                    counted = false;
+                    unsigned long long now = __builtin_amdgcn_s_memtime();
+                    dbg_busy += now - dbg_t;
+                    dbg_t = now;
+                }
+                // Idle polling must be gentle: thousands of wavefronts hammering the same L2 lines
+                // with agent-scope loads starve the producers. While the tail has not moved since
+                // the ring was last seen empty there is nothing to pop, so ONE load per poll
+                // suffices; polls back off exponentially (1 us .. ~0.2 ms).
+                bool try_pop = true;
+                if (empty_seen) {
+                    uint32_t tl = 0;
+                    if (lane == 0) tl = aldw(&c.pq[PQ_TAIL]);
+                    tl = rflu(tl);
+                    try_pop = tl != last_tail;
+                }
+                dbg_polls++;
+                if (try_pop && q_pop<DR>(c, hd, dom, lane)) {
+                    dbg_pop++;
+                    {
+                        unsigned long long now = __builtin_amdgcn_s_memtime();
+                        dbg_idle += now - dbg_t;
+                        dbg_t = now;
+                    }
+                    counted = true;
+                    have = true;
+                    polls = 0;
+                    backoff = 1u + ((unsigned)(wid + nodes_done) * 2654435761u >> 28);  // 1..16 us after work
+                    empty_seen = false;
+                } else {
+                    if (try_pop || (polls & 7u) == 7u) {
+                        // (a lost pop race also lands here: the check below re-reads head/tail)
+                        // done when no task is pending anywhere
+                        uint32_t act = 0, hd_ = 0, tl = 0, stop = 0;
+                        if (lane == 0) {
+                            act = aldw(&c.pq[PQ_PENDING]);
+                            hd_ = aldw(&c.pq[PQ_HEAD]);
+                            tl = aldw(&c.pq[PQ_TAIL]);
+                            stop = aldw(&c.pq[PQ_ABORT]) | aldw(&misc[MISC_ERROR * CST]);
+                        }
+                        act = rflu(act);
+                        hd_ = rflu(hd_);
+                        tl = rflu(tl);
+                        if (rflu(stop)) break;
+                        if (act == 0) break;
+                        if (hd_ == tl) {
+                            empty_seen = true;
+                            last_tail = tl;
+                        } else {
+                            empty_seen = false;  // somebody is mid-push/pop: look again soon
+                        }
+                    }
+                    if (++polls > (1u << 22)) {  // ~10 minutes of nothing: give up loudly
+                        if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_SPIN);
+                        break;
+                    }
+                    for (unsigned k = 0; k < backoff; k++) __builtin_amdgcn_s_sleep(40);  // ~1 us each
+                    if (backoff < (unsigned)c.park_cap && backoff < kMaxBackoff) backoff <<= 1;
+                    continue;
+                }
+            }
+        }
+        // ---- one search node
+        if ((nodes_done & 63u) == 63u) {  // a pool overflowed / somebody aborted: stop producing
+            uint32_t stop = 0;
+            if (lane == 0) stop = aldw(&c.pq[PQ_ABORT]) | aldw(&misc[MISC_ERROR * CST]);
+            if (rflu(stop)) break;
+        }
+        BranchOut bo;
+        LeafOut<DR> lo;
+        const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, wid + (int)nodes_done, bo, lo);
+        nodes_done++;
+        if (oc == OC_FAIL) {
+            have = false;
+        } else if (oc == OC_BRANCH) {
+            // upper child: shared ring while it is hungry (or my stack is full), else private stack
+            Dom<DR> up = dom;
+            up.set(bo.bvar, bo.D & ~bo.lowmask, lane);
+            NodeHdr uh = hd;
+            uh.seed = (uint32_t)(bo.bvar + 1);
+            bool shared = sp >= c.pstk_cap;
+            if (!shared && ((nodes_done & 3u) == 0 || nodes_done < 32u)) {
+                // share only while there are idle wavefronts that the ring cannot feed yet:
+                // in steady state (everybody busy) nothing goes through the shared words at all
+                int want = 0;
+                if (lane == 0) {
+                    const int ql = (int)(aldw(&c.pq[PQ_TAIL]) - aldw(&c.pq[PQ_HEAD]));
+                    const int busy = (int)aldw(&c.pq[PQ_PENDING]) - ql;  // tasks held by wavefronts
+                    want = ql < c.hungry - busy;                         // hungry = wavefronts in the grid
+
+                }
+                shared = rfl(want) != 0;
+            }
+            if (shared) shared = q_push<DR>(c, uh, up, lane);
+            if (shared) dbg_push++;
+            if (!shared) {
+                if (sp >= c.pstk_cap) {
+                    if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_QUEUE_FULL);
+                    break;
+                }
+                store_node<DR>(mystack + (size_t)sp * c.NS, c, uh.h0, uh.h1, (uint32_t)uh.set | (uh.seed << 16), uh.expire, up, lane);
+                sp++;
+            }
+            // continue with the lower child in registers
+            dom.set(bo.bvar, bo.D & bo.lowmask, lane);
+            hd.seed = (uint32_t)(bo.bvar + 1);
+            have = true;
+        } else if (oc == OC_MISS) {
+            uint32_t pi = 0;
+            if (lane == 0) pi = atomicAdd(&c.pq[PQ_PARKED], 1u);
+            pi = rflu(pi);
+            if ((int)pi >= c.park_cap) {
+                if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_PARK_FULL);
+                break;
+            }
+            store_node<DR>(c.parked + (size_t)pi * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
+            have = false;
+        } else {
+            const int ro = (wid + (int)nodes_done) % R;
+            CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, wid);
+            if (!co.ok) break;  // pool overflow: MISC_ERROR is set
+            if (co.is_new) {
+                // new state: go on with its first node right here
+                const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
+                hd.h0 = (uint32_t)gid;
+                hd.h1 = (uint32_t)(gid >> 32);
+                hd.set = co.set;
+                hd.seed = 0;
+                hd.expire = lo.new_expire;
+#pragma unroll
+                for (int q = 0; q < DR; q++) dom.r[q] = lo.nblk[q];
+                have = true;
+            } else {
+                have = false;
+            }
+        }
+    }
+    if (counted && lane == 0) atomicSub(&c.pq[PQ_PENDING], 1u);
+    if (lane == 0) {
+        dbg_idle += __builtin_amdgcn_s_memtime() - dbg_t;
+        add_stats(c, wid, ST_QPUSH, dbg_push);
+        add_stats(c, wid, ST_QPOP, dbg_pop);
+        add_stats(c, wid, ST_POLLS, dbg_polls);
+        add_stats(c, wid, ST_IDLE_CYC, dbg_idle);
+        add_stats(c, wid, ST_BUSY_CYC, dbg_busy);
+        add_stats(c, wid, ST_PSTACK_POP, dbg_ppop);
+        add_stats(c, wid, ST_WAVES_WORKED, nodes_done ? 1 : 0);
+    }
+}
+
 // ------------------------------------------------------------------ commit
 // Lookup-or-insert the state (set tag, signature) held lane-striped in `kw` (lane j = key word j)
 // and append the edge record (label `vals`, lane-striped like the domain block).
@@ -1413,6 +1730,7 @@ struct stcsp_engine {
     size_t lds_bytes = 0;
     int chunk_r = 0;  // max nodes taken per region per launch
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
+    int persist_blocks = 256 * 4;  // k_persist grid: must all be resident
 
     DevBuf<int> d_arr_data, d_code, d_miss;
     DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
@@ -1422,6 +1740,8 @@ struct stcsp_engine {
     int *h_miss = nullptr;      // pinned
     uint32_t cand_cap = 0;
     DevBuf<Plan> d_plan;
+    DevBuf<uint32_t> d_pq, d_ring, d_seq, d_pstack, d_parked;  // persistent mode
+    bool persist = false;    // STCSP_PERSIST=1: unsharded solves without budgets use k_persist (experimental)
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
     Ctx *h_ctx = nullptr;    // pinned staging copy
     Plan *h_plan = nullptr;  // pinned mirror of the plan header (everything before the stack)
@@ -1539,6 +1859,17 @@ struct stcsp_engine {
             if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
                 max_blocks = per_cu * prop.multiProcessorCount;
             if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
+            // the persistent kernel has its own register footprint
+            switch (DR) {
+                case 1: fn = img_in_lds ? (const void *)k_persist<1, true> : (const void *)k_persist<1, false>; break;
+                case 2: fn = img_in_lds ? (const void *)k_persist<2, true> : (const void *)k_persist<2, false>; break;
+                default: fn = img_in_lds ? (const void *)k_persist<4, true> : (const void *)k_persist<4, false>; break;
+            }
+            per_cu = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
+            if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
+                persist_blocks = per_cu * prop.multiProcessorCount;
+            if (const char *ev = getenv("STCSP_PBLOCKS")) if (atoi(ev) > 0) persist_blocks = atoi(ev);
         }
         return STCSP_OK;
     }
@@ -1614,6 +1945,7 @@ struct stcsp_engine {
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_PERSIST")) persist = atoi(ev) != 0;
         sync_ctx();
         return STCSP_OK;
     }
@@ -1656,6 +1988,20 @@ struct stcsp_engine {
         ctx.plan = d_plan.p;
         ctx.arena = d_arena.p;
         ctx.cand = d_cand.p;
+        ctx.pq = d_pq.p;
+        ctx.ring = d_ring.p;
+        ctx.seq = d_seq.p;
+        ctx.pstack = d_pstack.p;
+        ctx.parked = d_parked.p;
+    }
+    int flush_ctx() {
+        sync_ctx();
+        if (memcmp(h_ctx, &ctx, sizeof(Ctx)) != 0) {  // pools / program moved: refresh the device copy
+            HIPCHK(hipStreamSynchronize(stream));      // (the staging copy may still be in flight)
+            memcpy(h_ctx, &ctx, sizeof(Ctx));
+            HIPCHK(hipMemcpyAsync(d_ctx.p, h_ctx, sizeof(Ctx), hipMemcpyHostToDevice, stream));
+        }
+        return STCSP_OK;
     }
     static constexpr size_t kPlanHeader = offsetof(Plan, stack);
 
@@ -1823,12 +2169,7 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         const bool prof = opt.flags & STCSP_F_PROFILE;
         for (;;) {
-            sync_ctx();
-            if (memcmp(h_ctx, &ctx, sizeof(Ctx)) != 0) {  // pools / program moved: refresh the device copy
-                HIPCHK(hipStreamSynchronize(stream));      // (the staging copy may still be in flight)
-                memcpy(h_ctx, &ctx, sizeof(Ctx));
-                HIPCHK(hipMemcpyAsync(d_ctx.p, h_ctx, sizeof(Ctx), hipMemcpyHostToDevice, stream));
-            }
+            if ((rc = flush_ctx())) return rc;
             for (int k = 0; k < burst; k++) {
                 if (prof) {
                     if (ev_used == ev_pool.size()) {
@@ -1900,8 +2241,93 @@ struct stcsp_engine {
         return false;
     }
 
+    template <int DRT>
+    void launch_persist() {
+        if (img_in_lds)
+            hipLaunchKernelGGL((k_persist<DRT, true>), dim3(persist_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
+        else
+            hipLaunchKernelGGL((k_persist<DRT, false>), dim3(persist_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
+    }
+    // Persistent mode. Returns 1 when the run has to be redone round-based (a fixed-size pool
+    // overflowed: the round-based path grows pools between launches), 0 on success, < 0 on error.
+    int solve_persistent() {
+        const uint32_t qcap = 1u << 16;
+        const int pstk = 64, park_cap = 4096;
+        const size_t nwaves = (size_t)persist_blocks * 4;
+        if (!d_ring.p) {
+            HIPCHK(d_pq.alloc(PQ_WORDS));
+            HIPCHK(d_ring.alloc((size_t)qcap * ctx.NS));
+            HIPCHK(d_seq.alloc(qcap));
+            HIPCHK(d_parked.alloc((size_t)park_cap * ctx.NS));
+        }
+        if (d_pstack.n < nwaves * pstk * ctx.NS) HIPCHK(d_pstack.alloc(nwaves * pstk * ctx.NS));
+        ctx.qmask = qcap - 1;
+        ctx.pstk_cap = pstk;
+        ctx.park_cap = park_cap;
+        ctx.hungry = (int)nwaves;  // wavefronts in the grid (idle = hungry - active)
+        int rc = begin();  // common initialisation: cursors, statistics, table, root state 0
+        if (rc != STCSP_OK) return rc;
+        std::vector<uint32_t> seqs(qcap);
+        // the ring starts with the root node (written to the arena by begin())
+        std::vector<uint32_t> pending((size_t)ctx.NS);
+        HIPCHK(hipMemcpy(pending.data(), d_arena.p, (size_t)ctx.NS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        size_t n_pending = 1;
+        for (;;) {
+            // (re)load the ring with the pending nodes: slots [0, n) full, the rest empty
+            for (uint32_t i = 0; i < qcap; i++) seqs[i] = i < n_pending ? i + 1 : i;
+            std::vector<uint32_t> pq(PQ_WORDS, 0u);
+            pq[PQ_TAIL] = (uint32_t)n_pending;
+            pq[PQ_PENDING] = (uint32_t)n_pending;
+            HIPCHK(hipMemcpyAsync(d_seq.p, seqs.data(), qcap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_pq.p, pq.data(), PQ_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_ring.p, pending.data(), n_pending * ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            if ((rc = flush_ctx())) return rc;
+            HIPCHK(hipStreamSynchronize(stream));  // staging vectors are pageable
+            const bool prof = opt.flags & STCSP_F_PROFILE;
+            if (prof) {
+                if (ev_used == ev_pool.size()) {
+                    hipEvent_t e0, e1;
+                    HIPCHK(hipEventCreate(&e0));
+                    HIPCHK(hipEventCreate(&e1));
+                    ev_pool.emplace_back(e0, e1);
+                }
+                HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+            }
+            switch (DR) {
+                case 1: launch_persist<1>(); break;
+                case 2: launch_persist<2>(); break;
+                default: launch_persist<4>(); break;
+            }
+            HIPCHK(hipGetLastError());
+            if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
+            expand_launches++;
+            levels++;
+            HIPCHK(hipMemcpyAsync(pq.data(), d_pq.p, PQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            const uint32_t dev_err = h_ctl[L.misc0 + MISC_ERROR * CST], ab = pq[PQ_ABORT];
+            if (dev_err == ERR_EDGE_OVERFLOW || dev_err == ERR_STATE_OVERFLOW || ab == AB_QUEUE_FULL || ab == AB_PARK_FULL)
+                return 1;  // fixed-size pool too small for this instance: redo with growing pools
+            if (dev_err || ab) return fail(STCSP_E_INTERNAL, "persistent kernel stopped: device error %u, abort %u", dev_err, ab);
+            n_pending = pq[PQ_PARKED];
+            if (n_pending == 0) break;
+            // leaves waiting for a constraint-set translation: translate, then run them again
+            if ((rc = service_misses())) return rc;
+            pending.resize(n_pending * ctx.NS);
+            HIPCHK(hipMemcpy(pending.data(), d_parked.p, pending.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        return 0;
+    }
+
     int solve_unsharded() {
-        int rc = begin();
+        int rc;
+        if (persist && opt.time_limit_s <= 0 && opt.max_search_nodes <= 0) {
+            rc = solve_persistent();
+            if (rc < 0) return rc;
+            if (rc == 0) return finish();
+            // fall through: redo round-based
+        }
+        rc = begin();
         if (rc != STCSP_OK) return rc;
         rc = run_rounds();
         if (rc != STCSP_OK) return rc;
@@ -1924,6 +2350,10 @@ struct stcsp_engine {
         ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
         ctr.sweeps = (int64_t)tot[ST_SWEEPS];
         ctr.skipped_revisions = (int64_t)tot[ST_SKIPPED];
+        if (getenv("STCSP_DEBUG") && tot[ST_POLLS])
+            fprintf(stderr, "[persist] pushes %llu pops %llu private pops %llu polls %llu waves that worked %llu; idle Mcycles %.1f busy Mcycles %.1f\n",
+                    (unsigned long long)tot[ST_QPUSH], (unsigned long long)tot[ST_QPOP], (unsigned long long)tot[ST_PSTACK_POP],
+                    (unsigned long long)tot[ST_POLLS], (unsigned long long)tot[ST_WAVES_WORKED], tot[ST_IDLE_CYC] / 1e6, tot[ST_BUSY_CYC] / 1e6);
 #ifdef STCSP_PHASES
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: load %.0f sweep %.0f wave %.0f classify+emit %.0f commit %.0f total %.0f (nodes %llu)\n",
