@@ -1690,6 +1690,69 @@ __global__ void k_rehash(Ctx c, uint32_t n_states) {
     while (atomicCAS(&c.slots[pos], 0ull, want) != 0ull) pos = (pos + 1) & c.slot_mask;
 }
 
+// ------------------------------------------------------------------ export (unsharded runs)
+// The reference's ok/fail bookkeeping (src/solveralgorithm.cpp:857-874, 904-909) as an
+// edge-parallel fixpoint on the device (the host twin is okfix.hpp): repeatedly mark every
+// non-root state without a live out-edge as failed and kill the edges into it. Then the live
+// edges are compacted into structure-of-arrays buffers, so the host copies exactly the result
+// arrays of the C-ABI (no per-edge work on the host).
+struct EdgeView {
+    const uint32_t *edges;
+    uint32_t edge_cap;
+    int ES, N;
+    uint32_t pref[R + 1];  // prefix sums of the per-region record counts
+};
+__device__ __forceinline__ const uint32_t *edge_at(const EdgeView &v, uint32_t e) {
+    int r = 0;
+#pragma unroll
+    for (int step = R / 2; step >= 1; step >>= 1)
+        if (e >= v.pref[r + step]) r += step;
+    return v.edges + ((size_t)r * v.edge_cap + (e - v.pref[r])) * v.ES;
+}
+__global__ void k_post_outdeg(EdgeView v, uint32_t *outdeg, uint8_t *alive) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.pref[R]) return;
+    const uint32_t *er = edge_at(v, e);
+    alive[e] = 1;
+    atomicAdd(&outdeg[er[0]], 1u);  // unsharded: the global id is the local index
+}
+__global__ void k_post_mark(uint32_t n_states, const uint32_t *outdeg, uint8_t *fail, uint32_t *changed) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 || s >= n_states) return;  // the root is never marked (solveralgorithm.cpp:967-971)
+    if (!fail[s] && outdeg[s] == 0) {
+        fail[s] = 1;
+        *changed = 1u;
+    }
+}
+__global__ void k_post_kill(EdgeView v, uint8_t *alive, const uint8_t *fail, uint32_t *outdeg) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.pref[R] || !alive[e]) return;
+    const uint32_t *er = edge_at(v, e);
+    if (fail[er[2]]) {
+        alive[e] = 0;
+        atomicSub(&outdeg[er[0]], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void k_post_compact(EdgeView v, const uint8_t *alive, uint32_t *counter, long long *osrc,
+                                                       long long *odst, int32_t *oval) {
+    __shared__ uint32_t wcount[4], base;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const bool live = e < v.pref[R] && alive[e];
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) wcount[wib] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) base = atomicAdd(counter, wcount[0] + wcount[1] + wcount[2] + wcount[3]);
+    __syncthreads();
+    if (!live) return;
+    uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wib; w++) pos += wcount[w];
+    const uint32_t *er = edge_at(v, e);
+    osrc[pos] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
+    odst[pos] = (long long)er[2];
+    for (int k = 0; k < v.N; k++) oval[(size_t)pos * v.N + k] = (int32_t)er[4 + k];
+}
+
 // ------------------------------------------------------------------ host side
 template <typename T>
 struct DevBuf {
@@ -1765,6 +1828,16 @@ struct stcsp_engine {
     std::vector<int32_t> r_cid, r_sig, r_eval;
     std::vector<uint8_t> r_fail, r_issig;
     std::vector<int64_t> r_esrc, r_edst;
+    // device-side export (unsharded): compacted SoA on the device, pinned mirrors on the host
+    DevBuf<long long> d_osrc, d_odst;
+    DevBuf<int32_t> d_oval;
+    DevBuf<uint8_t> d_alive, d_fail;
+    DevBuf<uint32_t> d_outdeg, d_post;  // d_post: [0] changed flag, [1] live-edge counter
+    long long *h_osrc = nullptr, *h_odst = nullptr;
+    int32_t *h_oval = nullptr;
+    uint32_t *h_keys = nullptr;
+    uint8_t *h_fail = nullptr;
+    size_t h_edge_cap = 0, h_state_cap = 0;
 
     ~stcsp_engine() {
         for (auto &e : ev_pool) {
@@ -1774,6 +1847,11 @@ struct stcsp_engine {
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_plan) (void)hipHostFree(h_plan);
         if (h_ctx) (void)hipHostFree(h_ctx);
+        if (h_osrc) (void)hipHostFree(h_osrc);
+        if (h_odst) (void)hipHostFree(h_odst);
+        if (h_oval) (void)hipHostFree(h_oval);
+        if (h_keys) (void)hipHostFree(h_keys);
+        if (h_fail) (void)hipHostFree(h_fail);
         if (h_miss) (void)hipHostFree(h_miss);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -2457,10 +2535,143 @@ struct stcsp_engine {
         return read_plan();
     }
 
+    // unsharded export: ok-fixpoint + compaction on the device, result arrays land in pinned memory
+    int export_device(stcsp_result *res, stcsp_counters &ctr, size_t &E_out) {
+        const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N;
+        size_t E = 0;
+        EdgeView v{};
+        v.edges = d_edges.p;
+        v.edge_cap = ctx.edge_cap;
+        v.ES = ctx.ES;
+        v.N = N;
+        for (int r = 0; r < R; r++) {
+            v.pref[r] = (uint32_t)E;
+            E += edge_count[r];
+        }
+        v.pref[R] = (uint32_t)E;
+        if (E > 0xfffffff0ull) return fail(STCSP_E_NOMEM, "edge log too large for the device export");
+        if (d_alive.n < E) HIPCHK(d_alive.alloc(E + E / 4 + 256));
+        if (d_osrc.n < E) {
+            size_t cap = E + E / 4 + 256;
+            HIPCHK(d_osrc.alloc(cap));
+            HIPCHK(d_odst.alloc(cap));
+            HIPCHK(d_oval.alloc(cap * N));
+        }
+        if (d_fail.n < n_states) {
+            HIPCHK(d_fail.alloc((size_t)n_states + n_states / 4 + 256));
+            HIPCHK(d_outdeg.alloc((size_t)n_states + n_states / 4 + 256));
+        }
+        if (!d_post.p) HIPCHK(d_post.alloc(4));
+        if (h_edge_cap < E) {
+            if (h_osrc) (void)hipHostFree(h_osrc);
+            if (h_odst) (void)hipHostFree(h_odst);
+            if (h_oval) (void)hipHostFree(h_oval);
+            h_edge_cap = E + E / 4 + 256;
+            HIPCHK(hipHostMalloc((void **)&h_osrc, h_edge_cap * sizeof(long long)));
+            HIPCHK(hipHostMalloc((void **)&h_odst, h_edge_cap * sizeof(long long)));
+            HIPCHK(hipHostMalloc((void **)&h_oval, h_edge_cap * N * sizeof(int32_t)));
+        }
+        if (h_state_cap < n_states) {
+            if (h_keys) (void)hipHostFree(h_keys);
+            if (h_fail) (void)hipHostFree(h_fail);
+            h_state_cap = (size_t)n_states + n_states / 4 + 256;
+            HIPCHK(hipHostMalloc((void **)&h_keys, h_state_cap * KL * sizeof(uint32_t)));
+            HIPCHK(hipHostMalloc((void **)&h_fail, h_state_cap));
+        }
+        const bool dbg = getenv("STCSP_DEBUG") != nullptr;
+        auto tA = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!dbg) return;
+            (void)hipStreamSynchronize(stream);
+            auto tB = std::chrono::steady_clock::now();
+            fprintf(stderr, "[export] %-22s %.3f ms\n", what, std::chrono::duration<double>(tB - tA).count() * 1e3);
+            tA = tB;
+        };
+        HIPCHK(hipMemcpyAsync(h_keys, d_state_keys.p, (size_t)n_states * KL * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
+        HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
+        const unsigned eb = (unsigned)((E + 255) / 256), sb = (n_states + 255) / 256;
+        uint32_t live = 0;
+        if (E) {
+            hipLaunchKernelGGL(k_post_outdeg, dim3(eb), dim3(256), 0, stream, v, d_outdeg.p, d_alive.p);
+            for (int it = 0;; it++) {
+                hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
+                uint32_t changed = 0;
+                HIPCHK(hipMemcpyAsync(&changed, d_post.p, sizeof changed, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                if (!changed) break;
+                HIPCHK(hipMemsetAsync(d_post.p, 0, sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(k_post_kill, dim3(eb), dim3(256), 0, stream, v, d_alive.p, (const uint8_t *)d_fail.p, d_outdeg.p);
+                if (it > (int)n_states + 8) return fail(STCSP_E_INTERNAL, "ok-fixpoint did not converge");
+            }
+            lap("fixpoint");
+            hipLaunchKernelGGL(k_post_compact, dim3(eb), dim3(256), 0, stream, v, (const uint8_t *)d_alive.p, d_post.p + 1, d_osrc.p, d_odst.p, d_oval.p);
+            HIPCHK(hipGetLastError());
+            lap("compact");
+            HIPCHK(hipMemcpyAsync(&live, d_post.p + 1, sizeof live, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemcpyAsync(h_osrc, d_osrc.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_odst, d_odst.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_oval, d_oval.p, (size_t)live * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            // no edges at all: every non-root state is failed
+            hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
+        }
+        HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        lap("D2H result arrays");
+        r_cid.assign(n_states, 0);
+        r_sig.assign((size_t)n_states * std::max(sl, 0), 0);
+        int64_t ok_states = 0;
+        for (uint32_t i = 0; i < n_states; i++) {
+            uint32_t tag = h_keys[(size_t)i * KL];
+            r_cid[i] = (tag == kRootTag) ? 0 : (int32_t)tag;
+            for (int j = 0; j < sl; j++) r_sig[(size_t)i * sl + j] = (int32_t)h_keys[(size_t)i * KL + 1 + j];
+            if (i) ok_states += !h_fail[i];
+        }
+        ctr.dominance = (int64_t)live - ok_states;  // every ok non-root state is entered by exactly one creating leaf
+        lap("host key split");
+        res->state_fail = h_fail;
+        res->edge_src = (const int64_t *)h_osrc;
+        res->edge_dst = (const int64_t *)h_odst;
+        res->edge_values = h_oval;
+        E_out = live;
+        return STCSP_OK;
+    }
+
     int export_result(stcsp_result *res) {
         auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipSetDevice(device));
         const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N, ES = ctx.ES;
+        if (opt.world == 1 && !(opt.flags & STCSP_F_KEEP_RAW_EDGES) && !getenv("STCSP_HOST_EXPORT")) {
+            stcsp_counters ctr{};
+            int rcc = read_counters(ctr);
+            if (rcc != STCSP_OK) return rcc;
+            memset(res, 0, sizeof *res);
+            size_t E = 0;
+            rcc = export_device(res, ctr, E);
+            if (rcc != STCSP_OK) return rcc;
+            r_issig.assign(mgr.is_sig.begin(), mgr.is_sig.end());
+            res->n_states = n_states;
+            res->sig_len = sl;
+            res->n_sig_vars = mgr.n_sig;
+            res->n_until = mgr.n_until;
+            res->n_until_cons = mgr.n_until_cons;
+            res->state_cid = r_cid.data();
+            res->state_sig = r_sig.data();
+            res->n_edges = (int64_t)E;
+            res->n_vars = N;
+            res->n_constraint_sets = (int32_t)mgr.sets.size();
+            res->var_is_signature = r_issig.data();
+            res->root_final = mgr.n_until_cons == 0;
+            res->truncated = truncated;
+            seconds_export = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (getenv("STCSP_DEBUG")) fprintf(stderr, "[export] whole export_result    %.3f ms\n", seconds_export * 1e3);
+            ctr.seconds_export = seconds_export;
+            res->counters = ctr;
+            return STCSP_OK;
+        }
         std::vector<uint32_t> keys((size_t)n_states * KL);
         if (n_states) HIPCHK(hipMemcpy(keys.data(), d_state_keys.p, keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         r_cid.assign(n_states, 0);
