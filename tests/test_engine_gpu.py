@@ -168,3 +168,16 @@ def test_engine_persistent_mode_parity(stcsp, golden, monkeypatch):
         a, _ = finish(e, r)
         assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
         assert r.counters.levels <= 3  # launches: 1 + one per translation round
+
+
+def test_engine_array_validity_semantics(stcsp, RefOracle):
+    """Out-of-range array lookups (reference `valid` flag), also under branches that are not
+    taken: tabulated by the host evaluator and checked against the oracle."""
+    from test_oracle import ARR_EDGE_CASES
+    for text in ARR_EDGE_CASES:
+        m = stcsp.Model(text=text)
+        o = RefOracle(m)
+        ao, _ = finish(o, o.solve())
+        e = stcsp.Engine(m)
+        ae, _ = finish(e, e.solve())
+        assert ae.canonical() == ao.canonical(), text

@@ -112,3 +112,28 @@ def test_oracle_time_box(stcsp, RefOracle):
     o = RefOracle(m, max_search_nodes=5000)
     r = o.solve()
     assert r.truncated == 1 and 5000 <= r.counters.search_nodes <= 5100
+
+
+ARR_EDGE_CASES = [
+    # index out of range makes the comparison false (valid = false), so i is pruned to {0,1}
+    "arr T:{1,2}; var i:[0,3]; var v:[0,3]; v == T[i]; next i == (i + 1) % 2;",
+    # out-of-range lookup in the branch that is NOT taken must not invalidate the tuple
+    "arr T:{5,6,7}; var i:[0,4]; var v:[0,9]; v == if i lt 3 then T[i] else i; next i == i;",
+    # ... and `and` / `or` short-circuits guard it the same way
+    "arr T:{0,1}; var i:[0,3]; var b:[0,1]; b == ((i lt 2) and (T[i] eq 1)); next i == (i + b) % 4;",
+    "arr T:{0,1}; var i:[0,3]; var b:[0,1]; b == ((i ge 2) or (T[i] eq 1)); next i == (i + 1) % 4;",
+]
+
+
+@pytest.mark.parametrize("text", ARR_EDGE_CASES)
+def test_array_validity_semantics(stcsp, RefOracle, FrontierModel, text):
+    """solverValidateRe's `valid` flag (solveralgorithm.cpp:344-352, 396-397): the compiled
+    postfix program + liveness guards (frontier model) must agree with the tree-walking
+    restatement of the reference on out-of-range array lookups."""
+    m = stcsp.Model(text=text)
+    o = RefOracle(m)
+    ao, _ = finish(o, o.solve())
+    f = FrontierModel(m)
+    af, _ = finish(f, f.solve())
+    assert af.canonical() == ao.canonical()
+    assert ao.n_live_states > 1
