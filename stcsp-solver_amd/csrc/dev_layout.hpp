@@ -1,0 +1,118 @@
+// dev_layout.hpp -- device-visible structures of the engine: control-block layout, the device plan
+// (frontier segment stack + next-round arguments), kernel context. Included by engine.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "device_types.hpp"
+#include "stcsp_engine.h"
+namespace stcsp {
+namespace dev {
+
+
+constexpr int R = kRegions;
+constexpr int CST = kCursorStride;
+constexpr int kStatSlots = 64;
+constexpr int kStatWords = 24;
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
+       ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
+       ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED };
+constexpr int kMissStride = 66;  // set, nfirst, 64 values
+constexpr uint32_t kPending = 0xffffffffu;
+
+// control block (u32 words; every cursor on its own 64-byte line)
+struct CtlLayout {
+    int out0, cand0, edge0, misc0, words;  // out0: TWO sets of R cursors (round parity)
+    __host__ __device__ CtlLayout(int world) {
+        out0 = 0;
+        cand0 = 2 * R * CST;
+        edge0 = cand0 + world * R * CST;
+        misc0 = edge0 + R * CST;
+        words = misc0 + 8 * CST;
+    }
+    __host__ __device__ int out(int parity, int r) const { return out0 + (parity * R + r) * CST; }
+};
+
+// The frontier bookkeeping lives on the device: the last workgroup of every k_expand launch
+// accounts the round (finalize_round) and plans the next one (plan_next), so the host enqueues
+// bursts of rounds and synchronises once per burst.
+constexpr int kMaxSegments = 4096;
+enum PlanStatus : int { PS_RUN = 0, PS_DONE, PS_NEED_ARENA, PS_NEED_EDGES, PS_NEED_STATES, PS_NEED_TABLE, PS_HOST, PS_OUTBOX_FULL, PS_STACK_FULL };
+struct DevSegment {
+    unsigned long long base;  // word offset into the arena
+    unsigned cap;             // node slots per region
+    int count[R];
+    int pad;
+};
+struct Plan {
+    int status, parity, nslots, sp;
+    int take[R], count[R];
+    unsigned long long in_base, out_base, arena_top, arena_words, slot_cap;
+    unsigned in_cap, out_cap, edge_cap, state_cap, cand_cap, done_blocks;
+    int chunk_r, world;
+    long long rounds, open_total;
+    DevSegment stack[kMaxSegments];
+};
+enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
+enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
+       ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
+
+struct ImgOff {
+    int sets, cons, scope, strides, items, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
+        arr_off, words;
+};
+
+struct Ctx {
+    int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
+    // the compiled program: one contiguous image of 32-bit words (sections at the offsets in `o`),
+    // staged into LDS by every workgroup of k_expand when it fits; the bytecode and the
+    // user arrays (potentially large) stay in global memory
+    const uint32_t *img;
+    ImgOff o;
+    const int *code;
+    const int *arr_data;
+    unsigned long long *slots;
+    uint32_t slot_mask;
+    uint32_t *state_keys;
+    uint32_t state_cap;
+    uint32_t *ctl;
+    uint32_t *edges;
+    uint32_t edge_cap;  // records per region
+    int *miss;
+    int miss_cap;
+    unsigned long long *stats;
+    Plan *plan;
+    uint32_t *arena;
+    uint32_t *cand;  // outbox [owner][region] x cand_cap records (sharded runs)
+    // persistent mode (k_persist): shared ring of node records + per-wavefront private stacks
+    uint32_t *pq;      // control words, one per 64-byte line: see PQ_*
+    uint32_t *ring;    // qcap node records
+    uint32_t *seq;     // qcap sequence numbers (bounded MPMC queue)
+    uint32_t *pstack;  // [wavefront][pstk_cap] node records
+    uint32_t *parked;  // nodes waiting for a constraint-set translation
+    uint32_t qmask;    // qcap - 1
+    int pstk_cap, park_cap, hungry;
+};
+enum { PQ_HEAD = 0, PQ_TAIL = 16, PQ_PENDING = 32, PQ_ABORT = 48, PQ_PARKED = 64, PQ_WORDS = 80 };
+#ifndef STCSP_MAX_BACKOFF
+#define STCSP_MAX_BACKOFF 128
+#endif
+constexpr unsigned kMaxBackoff = STCSP_MAX_BACKOFF;
+enum { AB_NONE = 0, AB_QUEUE_FULL = 1, AB_PARK_FULL = 2, AB_SPIN = 3, AB_DEVICE_ERROR = 4 };
+
+struct ExpandArgs {  // per-round view, read from the device plan by every wavefront
+    const uint32_t *in_base;
+    uint32_t in_cap;
+    uint32_t *out_base;
+    uint32_t out_cap;
+    uint32_t *cand_base;
+    uint32_t cand_cap;
+    int parity;
+};
+
+struct CommitArgs {
+    const uint32_t *cand_base;  // contiguous array of candidate records
+    long long total;
+};
+
+}  // namespace dev
+}  // namespace stcsp

@@ -1,0 +1,752 @@
+// dev_propagate.hpp -- wave-level device code of one search node: helpers, the postfix interpreter,
+// the wavefront-cooperative revision (revise_point), the lane-per-item sweep and node classification
+// (process_node). Included by engine.hip only.
+#pragma once
+#include "dev_layout.hpp"
+namespace stcsp {
+namespace dev {
+// ------------------------------------------------------------------ device helpers
+// View of the program image: L = true -> the workgroup's LDS copy, false -> global memory.
+// u(): wave-uniform read (scalar load / broadcast LDS read), v(): per-lane read.
+template <bool L>
+struct Img {
+    const uint32_t *p;
+    __device__ __forceinline__ int v(int off) const { return (int)p[off]; }
+    __device__ __forceinline__ int u(int off) const;
+};
+// The compiled program (bytecode, descriptors, tables) is read-only for the lifetime of a launch
+// and indexed wave-uniformly: reading it through the constant address space makes hipcc emit
+// scalar loads (s_load_dword through the scalar cache) instead of 64-lane vector loads.
+typedef const __attribute__((address_space(4))) int *kptr;
+__device__ __forceinline__ int kload(const void *base, int idx) {
+    return ((kptr)(const __attribute__((address_space(1))) int *)base)[idx];
+}
+template <>
+__device__ __forceinline__ int Img<true>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)p[off]); }
+template <>
+__device__ __forceinline__ int Img<false>::u(int off) const { return kload(p, off); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// position of the k-th (0-based) set bit of m
+__device__ __forceinline__ int select_kth(uint32_t m, int k) {
+    for (int i = 0; i < k; i++) m &= m - 1;
+    return __ffs((int)m) - 1;
+}
+
+// The node's domain block, lane-striped over DR VGPRs: word idx lives in r[idx >> 6], lane idx & 63.
+template <int DR>
+struct Dom {
+    uint32_t r[DR];
+    __device__ __forceinline__ uint32_t get(int idx) const {  // idx wave-uniform
+        uint32_t v = r[0];
+#pragma unroll
+        for (int q = 1; q < DR; q++)
+            if ((idx >> 6) == q) v = r[q];
+        return rdlane(v, idx & 63);
+    }
+    __device__ __forceinline__ uint32_t gather(int idx) const {  // idx per lane
+        uint32_t out = 0;
+#pragma unroll
+        for (int q = 0; q < DR; q++) {
+            uint32_t t = (uint32_t)__shfl((int)r[q], idx & 63, 64);
+            if ((idx >> 6) == q) out = t;
+        }
+        return out;
+    }
+    __device__ __forceinline__ void set(int idx, uint32_t val, int lane) {  // idx wave-uniform
+#pragma unroll
+        for (int q = 0; q < DR; q++)
+            if ((idx >> 6) == q && lane == (idx & 63)) r[q] = val;
+    }
+};
+
+#ifdef STCSP_PHASES
+#define PHASE_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define PHASE_NOW() 0ull
+#endif
+struct WaveStats {
+    unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
+    unsigned long long cyc_sweep = 0, cyc_wave = 0;
+    unsigned long long evals = 0;
+};
+
+// Evaluate one constraint program on this lane's tuple (the role of solverValidateRe,
+// reference src/solveralgorithm.cpp:336-424). varinfo/curval are per-lane registers indexed by
+// scope position: varinfo = 1 + slot for lane-enumerated variables (value in lds_vals), 0 for
+// wave-uniform ones (value in curval).
+template <bool L>
+__device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_valid, int lane, uint32_t varinfo, int curval,
+                            const int *lds_vals, int *lds_stk) {
+    int t = 0, sp = 0;
+    bool valid = true;
+    uint32_t dead = 0;
+    for (;;) {
+        int w = kload(c.code, pc++);
+        int op = w & 255, arg = w >> 8;
+        switch (op) {
+            case OP_END: return t;
+            case OP_CONST:
+                lds_stk[sp * 64 + lane] = t;
+                sp++;
+                t = kload(c.code, pc++);
+                break;
+            case OP_VAR: {
+                lds_stk[sp * 64 + lane] = t;
+                sp++;
+                uint32_t info = rdlane(varinfo, arg);
+                if (info)
+                    t = lds_vals[(info - 1) * 64 + lane];
+                else
+                    t = (int)rdlane((uint32_t)curval, arg);
+                break;
+            }
+            case OP_ARR: {
+                int off = P.u(c.o.arr_off + arg), size = P.u(c.o.arr_off + arg + 1) - off;
+                bool inr = (unsigned)t < (unsigned)size;
+                if (!inr && dead == 0) valid = false;
+                t = inr ? c.arr_data[off + t] : 0;
+                break;
+            }
+            case OP_ABS: t = t < 0 ? (int)(0u - (unsigned)t) : t; break;
+            case OP_NOT: t = (t == 0); break;
+            case OP_MASK_T:
+            case OP_MASK_F: {
+                int v = arg == 0 ? t : lds_stk[(sp - arg) * 64 + lane];
+                bool live = (op == OP_MASK_T) ? (v != 0) : (v == 0);
+                dead = (dead << 1) | (live ? 0u : 1u);
+                break;
+            }
+            case OP_MASK_POP: dead >>= 1; break;
+            case OP_SEL_IF: {
+                int b = t, a = lds_stk[(sp - 1) * 64 + lane], cnd = lds_stk[(sp - 2) * 64 + lane];
+                sp -= 2;
+                t = cnd ? a : b;
+                break;
+            }
+            case OP_SEL_AND: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = a ? t : 0;
+                break;
+            }
+            case OP_SEL_OR: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = a ? 1 : t;
+                break;
+            }
+            case OP_SEL_IMPLY: {
+                int a = lds_stk[--sp * 64 + lane];
+                t = (a == 0) ? 1 : (a <= t);
+                break;
+            }
+            default: {
+                int b = t, a = lds_stk[--sp * 64 + lane], r = 0;
+                switch (op) {
+                    case OP_ADD: r = (int)((unsigned)a + (unsigned)b); break;
+                    case OP_SUB: r = (int)((unsigned)a - (unsigned)b); break;
+                    case OP_MUL: r = (int)((unsigned)a * (unsigned)b); break;
+                    case OP_DIV: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a / b; break;
+                    case OP_MOD: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a % b; break;
+                    case OP_LT: r = a < b; break;
+                    case OP_GT: r = a > b; break;
+                    case OP_LE: r = a <= b; break;
+                    case OP_GE: r = a >= b; break;
+                    case OP_EQ: r = a == b; break;
+                    case OP_NE: r = a != b; break;
+                    default: break;
+                }
+                t = (uses_valid && !valid) ? 0 : r;
+                break;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// position of the k-th (0-based) set bit of m, branch-free (k < popcount(m))
+__device__ __forceinline__ int select_kth_fast(uint32_t m, int k) {
+    int pos = 0, cnt;
+    cnt = __popc(m & 0xffffu);
+    if (k >= cnt) { k -= cnt; pos += 16; m >>= 16; }
+    cnt = __popc(m & 0xffu);
+    if (k >= cnt) { k -= cnt; pos += 8; m >>= 8; }
+    cnt = __popc(m & 0xfu);
+    if (k >= cnt) { k -= cnt; pos += 4; m >>= 4; }
+    cnt = __popc(m & 0x3u);
+    if (k >= cnt) { k -= cnt; pos += 2; m >>= 2; }
+    if (k >= (int)(m & 1u)) pos += 1;
+    return pos;
+}
+// x / d for 0 <= x < 64, 1 <= d <= 64 via one reciprocal (exact: (x + 0.5) / d is never within
+// 1/128 of an integer, far above float error)
+__device__ __forceinline__ int small_div(int x, int d) {
+    return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+
+// Enforce one point constraint at one time point: afterwards every remaining value of every
+// scope variable has a supporting tuple (generalised arc consistency on this constraint; the
+// reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
+// Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
+template <int DR, bool L>
+__device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc) {
+    const int s = C.scope_len;
+    // per-lane view of scope variable j = lane
+    int var = 0;
+    if (lane < s) var = G.v(c.o.scope + C.scope_off + lane);
+    uint32_t D = dom.gather(p * c.N + var);
+    if (lane >= s) D = 0;
+    const int n = lane < s ? __popc(D) : 1;
+    if (__ballot(lane < s && n == 0)) return false;
+    const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
+    const bool use_bitmap = C.bitmap_off >= 0;
+    const int mystride = (use_bitmap && lane < s) ? G.v(c.o.strides + C.stride_off + lane) : 0;
+
+    // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
+    // multiply to <= 64 are enumerated ACROSS LANES (lane index = mixed-radix tuple index), the rest
+    // ("high") are stepped wave-uniformly by an odometer. Singletons are just constants.
+    uint32_t varinfo = 0;   // scope lane j: 1 + slot if low
+    int pairbase = 0;       // scope lane j: first pair lane of low var j
+    int pst = 1, pn = 1, pk = 0;  // pair lane: stride / radix / digit it stands for
+    int lane_part = 0;      // tuple lane: bitmap index contribution of the low variables
+    int P = 1, nlow = 0, npairs = 0;
+    unsigned long long highmask = 0, lowmask = 0;
+    int maxn = 1;
+    for (unsigned long long m = __ballot(lane < s && n > 1); m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const int nj = (int)rdlane((uint32_t)n, j);
+        if (nlow < kMaxLowVars && P * nj <= 64) {
+            const uint32_t Dj = rdlane(D, j);
+            const int q = small_div(lane, P);
+            const int digit = q - nj * small_div(q, nj);
+            const int bitpos = select_kth_fast(Dj, digit);
+            lds_vals[nlow * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
+            if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
+            if (lane == j) {
+                varinfo = 1 + nlow;
+                pairbase = npairs;
+            }
+            if (lane >= npairs && lane < npairs + nj) {
+                pst = P;
+                pn = nj;
+                pk = lane - npairs;
+            }
+            lowmask |= 1ull << j;
+            nlow++;
+            P *= nj;
+            npairs += nj;
+        } else {
+            highmask |= 1ull << j;
+            if (nj > maxn) maxn = nj;
+        }
+    }
+    const bool active = lane < P;
+    const bool pairlane = lane < npairs;
+    // pair lane (q,k): the set of tuple lanes whose digit of low variable q equals k is periodic
+    // in the lane index -- build it arithmetically (no ballots)
+    unsigned long long M = 0;
+    if (pairlane) {
+        M = ((1ull << pst) - 1ull) << (pk * pst);
+        int sh = pst * pn;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            if (sh < 64) M |= M << sh;
+            sh <<= 1;
+        }
+        if (P < 64) M &= (1ull << P) - 1ull;
+    }
+    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the
+    // wave-uniform part of that product (the odometer range) is larger than the budget the
+    // revision could never finish, so it is skipped outright. This keeps propagation sound (no
+    // value is ever removed without proof) and the search complete: at a leaf every variable is a
+    // singleton, the product is 1 and the constraint is checked exactly -- the same argument that
+    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield
+    // the same automaton.
+    {
+        const unsigned long long budget = use_bitmap ? kBudgetBitmapIters : kBudgetCodeIters;
+        unsigned long long total_hi = 1;
+        for (unsigned long long hm = highmask; hm && total_hi <= budget; hm &= hm - 1)
+            total_hi *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)hm) - 1);
+        if (total_hi > budget) {
+            if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+            ws.skipped++;
+            return true;
+        }
+    }
+    bool hit = false;   // pair lanes: this (low var, digit) has a support
+    uint32_t hs = 0;    // scope lanes (high vars): supported value bits
+    int digit_h = 0;    // scope lanes (high vars): odometer digit
+    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;
+    int curval = vlb + curbit;
+    const bool is_high = (highmask >> lane) & 1ull;
+    // bitmap index contribution of the singleton variables (constant for this revision)
+    int base_sum = 0;
+    if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit * mystride : 0);
+    ws.revs++;
+    ws.wave_revs++;
+    const unsigned nact = (unsigned)P;
+    // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
+    // value of every high variable appears once, so loose constraints finish here.
+    // stage B: exhaustive odometer over the high variables, early exit once all is supported.
+    bool any_sat = false;
+    unsigned long long iters = 0;
+    int stage_a_left = highmask ? maxn : 1;
+    bool stage_b = false;
+    for (;;) {
+        if (stage_a_left > 0) {
+            if (is_high) {
+                int it = maxn - stage_a_left;
+                curbit = select_kth_fast(D, it - n * small_div(it, n));
+                curval = vlb + curbit;
+            }
+            stage_a_left--;
+        } else if (!stage_b) {
+            stage_b = true;  // first exhaustive tuple block: all high digits 0
+            if (is_high) {
+                digit_h = 0;
+                curbit = __ffs((int)D) - 1;
+                curval = vlb + curbit;
+            }
+        }
+        int res;
+        if (use_bitmap) {
+            int bit = lane_part + base_sum;
+            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+                const int j = __ffsll((long long)hm) - 1;
+                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
+            }
+            res = active ? (int)(((uint32_t)G.v(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
+        } else {
+            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        }
+        ws.evals += nact;
+        const unsigned long long sm = __ballot(active && res != 0);
+        if (sm) {
+            any_sat = true;
+            if (pairlane && (M & sm)) hit = true;
+            if (is_high) hs |= 1u << curbit;
+        }
+        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
+        if (stage_a_left > 0) continue;
+        if (!highmask) break;  // no high variables: the lanes covered the whole product
+        if (!stage_b) continue;
+        // advance the odometer (wave-uniform carry chain over the high variables)
+        bool carry = true;
+        for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
+            const int j = __ffsll((long long)hm) - 1;
+            int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
+            const int nj = (int)rdlane((uint32_t)n, j);
+            if (dj == nj)
+                dj = 0;
+            else
+                carry = false;
+            if (lane == j) {
+                digit_h = dj;
+                curbit = select_kth_fast(D, dj);
+                curval = vlb + curbit;
+            }
+        }
+        if (carry) break;  // wrapped around: product exhausted
+        if (++iters > (1ull << 22)) {
+            if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            return false;
+        }
+    }
+    // --- write back. No satisfying tuple at all: wipe-out. Otherwise singletons are supported by
+    // construction and only the enumerated / stepped variables can lose values.
+    if (!any_sat) return false;
+    const unsigned long long hitmask = __ballot(pairlane && hit);
+    for (unsigned long long m = lowmask | highmask; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const uint32_t Dj = rdlane(D, j);
+        uint32_t newD;
+        if ((lowmask >> j) & 1ull) {
+            const uint32_t dig = (uint32_t)(hitmask >> (int)rdlane((uint32_t)pairbase, j));
+            bool keep = false;
+            if (lane < 32 && ((Dj >> lane) & 1u)) keep = (dig >> __popc(Dj & ((1u << lane) - 1u))) & 1u;
+            newD = (uint32_t)__ballot(keep);
+        } else {
+            newD = rdlane(hs, j);
+        }
+        if (newD == 0) return false;
+        if (newD != Dj) {
+            const int vj = (int)rdlane((uint32_t)var, j);
+            dom.set(p * c.N + vj, newD, lane);
+            if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
+            if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
+        }
+    }
+    // one revision is a fixpoint for this constraint at this point: no need to revisit it for
+    // its own changes (supports are whole tuples of surviving values)
+    if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+    return true;
+}
+
+template <bool L>
+__device__ __forceinline__ void load_set(const Ctx &c, const Img<L> &P, int set, SetDesc &S) {
+    int *dst = (int *)&S;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = P.u(c.o.sets + set * (int)(sizeof(SetDesc) / 4) + i);
+}
+template <bool L>
+__device__ __forceinline__ void load_con(const Ctx &c, const Img<L> &P, int idx, ConDesc &C) {
+    int *dst = (int *)&C;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = P.u(c.o.cons + idx * (int)(sizeof(ConDesc) / 4) + i);
+}
+
+__device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
+    if (v) atomicAdd(&c.stats[(gw % kStatSlots) * kStatWords + which], v);
+}
+
+template <int DR>
+__device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
+                                           const Dom<DR> &dom, int lane) {
+    if (lane < 4) dst[lane] = lane == 0 ? h0 : (lane == 1 ? h1 : (lane == 2 ? h2 : h3));
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.NK) dst[4 + idx] = dom.r[q];
+    }
+}
+
+enum Outcome : int { OC_FAIL = 0, OC_BRANCH, OC_MISS, OC_LEAF };
+struct NodeHdr {
+    uint32_t h0, h1;  // src state (global id)
+    int set;          // constraint set index
+    uint32_t seed;    // dirty seed (see k_expand)
+    uint32_t expire;  // until-expire bits
+};
+struct BranchOut {
+    int bvar;
+    uint32_t D, lowmask;  // children: D & lowmask, D & ~lowmask at word (0, bvar)
+};
+template <int DR>
+struct LeafOut {
+    uint32_t kw;            // lane j: key word j = [next set tag, signature...]
+    unsigned long long h;   // key hash
+    int next_set, owner;
+    uint32_t next_tag, new_expire;
+    uint32_t evals[DR];     // edge label (Edge::values), lane-striped
+    uint32_t nblk[DR];      // time-advanced block, lane-striped
+};
+struct CommitOut {
+    uint32_t idx;  // local state index
+    bool is_new, ok;
+    int set;
+};
+template <int DR>
+__device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, unsigned long long h, uint32_t s0, uint32_t s1,
+                                  int set, uint32_t tag, const uint32_t (&vals)[DR], int stat_slot);
+template <int DR>
+__device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
+                                const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]);
+
+// ------------------------------------------------------------------ one search node
+// Propagate the block in `dom` to its fixpoint under the node's constraint set and classify the
+// node like solverSolveRe does: failed / branch / leaf (or "miss": a leaf whose constraint-set
+// translation the host has not provided yet). Outputs stay in registers; the callers (the
+// round-based k_expand and the persistent k_persist) decide where children and leaves go.
+template <int DR, bool L>
+__device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, Dom<DR> &dom,
+                            const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
+    const CtlLayout L_(c.world);
+    uint32_t *misc = c.ctl + L_.misc0;
+    const unsigned long long t_start = PHASE_NOW();
+    (void)t_start;
+    const int set = hd.set;
+    const uint32_t seed = hd.seed, expire = hd.expire;
+    SetDesc S;
+    load_set<L>(c, P, set, S);
+
+    // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). Work items
+    // are (constraint, time point) pairs; the dirty mask is lane-striped (lane w holds word w).
+    // Items [0, nsmall) -- X == next Y arcs, until checks and small extensional point constraints --
+    // are revised ONE ITEM PER LANE against a snapshot of the block, their prunings ANDed together
+    // through an LDS copy (a Jacobi sweep); the remaining items are revised by the whole
+    // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
+    WaveStats ws;
+    const unsigned long long t_loaded = PHASE_NOW();
+    (void)t_loaded;
+    int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
+    uint32_t dirtyw = 0;
+    if (lane < S.iw) {
+        if (seed == 0) {
+            int left = S.nitems - lane * 32;
+            dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+        } else if (seed != 0xffffu) {
+            dirtyw = (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (int)(seed - 1) * S.iw + lane);  // word (0, seed var)
+        }
+    }
+    uint32_t smallmask = 0;
+    if (lane < S.iw) {
+        int left = S.nsmall - lane * 32;
+        smallmask = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+    }
+    bool consistent = true;
+    unsigned guard = 0;
+    // LDS copy of the block (AND-accumulator of the sweeps); kept equal to `dom` between sweeps.
+    // Only this wavefront touches it and a wavefront's LDS operations execute in order, so
+    // wavefront-scope fences (compiler ordering only) are enough.
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        if (idx < c.NK) ldom[idx] = (int)dom.r[q];
+    }
+    while (consistent) {
+        if (__ballot((dirtyw & smallmask) != 0)) {
+            const unsigned long long t_sw = PHASE_NOW();
+            // ---- lane-parallel sweep over the dirty small items
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bool lfail = false;
+            ws.sweeps++;
+            const int npass = (S.nsmall + 63) >> 6;
+            for (int t = 0; t < npass; t++) {
+                const int item = t * 64 + lane;
+                const uint32_t dw0 = rdlane(dirtyw, (2 * t) & 63), dw1 = rdlane(dirtyw, (2 * t + 1) & 63);
+                const uint32_t dw = lane < 32 ? dw0 : dw1;
+                const bool isd = item < S.nsmall && ((dw >> (item & 31)) & 1u);
+                unsigned long long dmask = __ballot(isd);
+                if (!dmask) continue;
+                ws.revs += (unsigned)__popcll(dmask);
+                ItemDesc it;
+                {
+                    const int ioff = c.o.items + (S.item_begin + (isd ? item : 0)) * (int)(sizeof(ItemDesc) / 4);
+                    int *dst = (int *)&it;
+#pragma unroll
+                    for (int k = 0; k < (int)(sizeof(ItemDesc) / 4); k++) dst[k] = P.v(ioff + k);
+                }
+                // gathers are executed by every lane (cross-lane reads need the source lanes active)
+                uint32_t D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
+                uint32_t D2 = dom.gather(it.idx[2]), D3 = dom.gather(it.idx[3]);
+                if (isd) {
+                    if (it.type == IT_NEXT) {
+                        // X == next Y <=> X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
+                        const int sh = it.aux;
+                        uint32_t Yal = sh >= 0 ? (sh < 32 ? D1 >> sh : 0u) : (-sh < 32 ? D1 << -sh : 0u);
+                        uint32_t m = D0 & Yal;
+                        uint32_t newY = sh >= 0 ? (sh < 32 ? m << sh : 0u) : (-sh < 32 ? m >> -sh : 0u);
+                        if (m == 0) lfail = true;
+                        if (m != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], m);
+                        if (newY != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], newY);
+                    } else if (it.type == IT_UNTIL) {
+                        if (!((expire >> it.aux) & 1u) && __popc(D0) == 1 && __popc(D1) == 1) {
+                            int vx = P.v(c.o.var_lb + it.idx[0]) + __ffs((int)D0) - 1, vy = P.v(c.o.var_lb + it.idx[1]) + __ffs((int)D1) - 1;
+                            if (vx != 1 && vy != 1) lfail = true;
+                        }
+                    } else {
+                        // small extensional constraint: one row of allowed word-variable values per
+                        // tuple of the other (<= 3) variables; scan the rows of the current product
+                        if (it.arity < 2) D1 = 1u;
+                        if (it.arity < 3) D2 = 1u;
+                        if (it.arity < 4) D3 = 1u;
+                        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                        const int tab = c.o.tables + it.toff;
+                        unsigned nev = 0;
+                        for (uint32_t m3 = D3; m3; m3 &= m3 - 1) {
+                            const int b3 = __ffs((int)m3) - 1;
+                            for (uint32_t m2 = D2; m2; m2 &= m2 - 1) {
+                                const int b2 = __ffs((int)m2) - 1;
+                                const int base = it.r1 * (b2 + it.r2 * b3);
+                                for (uint32_t m1 = D1; m1; m1 &= m1 - 1) {
+                                    const int b1 = __ffs((int)m1) - 1;
+                                    const uint32_t row = (uint32_t)P.v(tab + base + b1) & D0;
+                                    nev++;
+                                    if (row) {
+                                        s0 |= row;
+                                        s1 |= 1u << b1;
+                                        s2 |= 1u << b2;
+                                        s3 |= 1u << b3;
+                                    }
+                                }
+                            }
+                        }
+                        ws.evals += nev;
+                        if (s0 == 0) lfail = true;
+                        if (s0 != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], s0);
+                        if (it.arity > 1 && s1 != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], s1);
+                        if (it.arity > 2 && s2 != D2) atomicAnd((unsigned *)&ldom[it.idx[2]], s2);
+                        if (it.arity > 3 && s3 != D3) atomicAnd((unsigned *)&ldom[it.idx[3]], s3);
+                    }
+                }
+            }
+            dirtyw &= ~smallmask;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (__ballot(lfail)) {
+                consistent = false;
+                break;
+            }
+            // read the intersection back; every changed word re-dirties the items that read it
+#pragma unroll
+            for (int q = 0; q < DR; q++) {
+                int idx = q * 64 + lane;
+                uint32_t nd = idx < c.NK ? (uint32_t)ldom[idx] : dom.r[q];
+                if (__ballot(idx < c.NK && nd == 0)) consistent = false;
+                unsigned long long cm = __ballot(nd != dom.r[q]);
+                dom.r[q] = nd;
+                while (cm) {
+                    int l = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    if (lane < S.iw) dirtyw |= (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (q * 64 + l) * S.iw + lane);
+                }
+            }
+            if (++guard > (1u << 20)) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+                consistent = false;
+            }
+            ws.cyc_sweep += PHASE_NOW() - t_sw;
+            continue;
+        }
+        const unsigned long long t_wv = PHASE_NOW();
+        unsigned long long dm = __ballot(dirtyw != 0);
+        if (!dm) break;
+        int wl = __ffsll((long long)dm) - 1;
+        uint32_t word = rdlane(dirtyw, wl);
+        int b = __ffs((int)word) - 1;
+        int item = wl * 32 + b;
+        if (lane == wl) dirtyw &= ~(1u << b);
+        const int ibase = c.o.items + (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
+        const int ipoint = P.u(ibase + 1), icon = P.u(ibase + 2);
+        ConDesc C;
+        load_con<L>(c, P, icon, C);
+        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc);
+        ws.cyc_wave += PHASE_NOW() - t_wv;
+        if (++guard > (1u << 20)) {
+            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            consistent = false;
+        }
+    }
+    if (lane == 0) {
+        add_stats(c, gw, ST_NODES, 1);
+        add_stats(c, gw, ST_REVS, ws.revs);
+        add_stats(c, gw, ST_EVALS, ws.evals);
+        add_stats(c, gw, ST_WAVEREVS, ws.wave_revs);
+        add_stats(c, gw, ST_SWEEPS, ws.sweeps);
+        add_stats(c, gw, ST_SKIPPED, ws.skipped);
+#ifdef STCSP_PHASES
+        add_stats(c, gw, ST_CYC_LOAD, t_loaded - t_start);
+        add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
+        add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
+#endif
+    }
+    const unsigned long long t_prop = PHASE_NOW();
+    (void)t_prop;
+    if (!consistent) {
+        if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
+        return OC_FAIL;
+    }
+
+    // ---- classify (solverGetFirstUnboundVar, src/solver.cpp:41-53): first variable, in queue
+    // order, whose time-0 domain is not a singleton
+    int bvar = -1;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        unsigned long long m = __ballot(idx < c.N && __popc(dom.r[q]) > 1);
+        if (bvar < 0 && m) bvar = q * 64 + __ffsll((long long)m) - 1;
+    }
+    if (bvar >= 0) {
+        // bisect [lb,ub] of the branching variable (variableSplitLower/Upper, variable.cpp:52-67)
+        const uint32_t D = dom.get(bvar);
+        const int lo_ = __ffs((int)D) - 1, hi_ = 31 - __clz((int)D);
+        const int mid = lo_ + (hi_ - lo_) / 2;
+        bo.bvar = bvar;
+        bo.D = D;
+        bo.lowmask = (mid >= 31) ? 0xffffffffu : ((2u << mid) - 1u);
+        return OC_BRANCH;
+    }
+
+    // ---- leaf: every variable has a single time-0 value (solveralgorithm.cpp:739-910)
+    // (1) next constraint set: per-leaf translation (:755-805) via the transition table
+    int next_set = set;
+    if (!S.self_loop) {
+        int fv = 0;
+        if (lane < S.nfirst) {
+            int v = P.v(c.o.firstvars + S.first_off + lane);
+            fv = v;
+        }
+        uint32_t fd = dom.gather(fv);  // time-0 word of that variable
+        int fval = (lane < S.nfirst) ? P.v(c.o.var_lb + fv) + __ffs((int)fd) - 1 : 0;
+        next_set = -1;
+        for (int t = 0; t < S.trans_count && next_set < 0; t++) {
+            int voff = P.u(c.o.trans + (S.trans_begin + t) * 2);
+            bool ne = lane < S.nfirst && P.v(c.o.transvals + voff + lane) != fval;
+            if (!__ballot(ne)) next_set = P.u(c.o.trans + (S.trans_begin + t) * 2 + 1);
+        }
+        if (next_set < 0) {
+            // unknown transition: park the node again and tell the host which translation is needed
+            uint32_t mi = 0;
+            if (lane == 0) mi = atomicAdd(&misc[MISC_NMISS * CST], 1u);
+            mi = rflu(mi);
+            if ((int)mi < c.miss_cap) {
+                int *rec = c.miss + (size_t)mi * kMissStride;
+                if (lane == 0) {
+                    rec[0] = set;
+                    rec[1] = S.nfirst;
+                }
+                if (lane < S.nfirst) rec[2 + lane] = fval;
+            }
+            if (lane == 0) add_stats(c, gw, ST_REQUEUE, 1);
+            return OC_MISS;
+        }
+    }
+    const uint32_t next_tag = (uint32_t)P.u(c.o.sets + next_set * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
+    // (2) signature (:812-837): signature variables in queue order, then one sticky flag per until
+    uint32_t new_expire = expire;
+    uint32_t kw = 0;  // lane j holds key word j: [tag, sig...]
+    {
+        int sv = 0;
+        if (lane >= 1 && lane <= c.n_sig) sv = P.v(c.o.sig_vars + lane - 1);
+        uint32_t sd = dom.gather(sv);
+        if (lane >= 1 && lane <= c.n_sig) kw = (uint32_t)(P.v(c.o.var_lb + sv) + __ffs((int)sd) - 1);
+        for (int u = 0; u < c.n_until_cons; u++) {
+            int y = P.u(c.o.until_y + u);
+            uint32_t DY = dom.get(y);
+            bool ex = (expire >> u) & 1u;
+            if (!ex && P.u(c.o.var_lb + y) + __ffs((int)DY) - 1 == 1) {
+                ex = true;
+                new_expire |= 1u << u;
+            }
+            if (lane == 1 + c.n_sig + u) kw = ex ? 1u : 0u;
+        }
+        if (lane == 0) kw = next_tag;
+    }
+    // (3) owner shard = hash(key) % world
+    unsigned long long h = kHashSeed;
+    for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
+    h = mix_final(h);
+    lo.kw = kw;
+    lo.h = h;
+    lo.next_set = next_set;
+    lo.next_tag = next_tag;
+    lo.new_expire = new_expire;
+    lo.owner = (int)((h >> 40) % (unsigned)c.world);
+    // edge label (Edge::values) and the time-advanced block (variableAdvanceOneTimeStep,
+    // variable.cpp:94-108: point p <- point p+1, last point <- [lb,ub]), lane-striped
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        int idx = q * 64 + lane;
+        lo.evals[q] = idx < c.N ? (uint32_t)(P.v(c.o.var_lb + idx) + __ffs((int)dom.r[q]) - 1) : 0u;
+        uint32_t shifted = dom.gather(idx + c.N < c.NK ? idx + c.N : 0);
+        uint32_t nb = 0;
+        if (idx < c.NK) {
+            int p = idx / c.N, v = idx - p * c.N;
+            nb = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
+        }
+        lo.nblk[q] = nb;
+    }
+    if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+    return OC_LEAF;
+}
+
+}  // namespace dev
+}  // namespace stcsp
