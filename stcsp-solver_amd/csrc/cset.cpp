@@ -496,6 +496,7 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
         it.r1 = others.size() > 0 ? size[others[0]] : 1;
         it.r2 = others.size() > 1 ? size[others[1]] : 1;
         int r3 = others.size() > 2 ? size[others[2]] : 1;
+        it.aux = (int32_t)rows;  // number of table rows = r1 * r2 * r3
         // idx[] carries scope positions here; the caller turns them into block word indices
         it.idx[0] = w;
         for (size_t k = 0; k < 3; k++) it.idx[1 + k] = k < others.size() ? others[k] : -1;

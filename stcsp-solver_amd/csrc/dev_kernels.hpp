@@ -19,6 +19,8 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     const int ro = (i + r) % R;
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
+    const unsigned long long t_a = PHASE_NOW();
+    (void)t_a;
     const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
     Dom<DR> dom;
 #pragma unroll
@@ -39,7 +41,26 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     hd.expire = rflu(node[3]);
     BranchOut bo;
     LeafOut<DR> lo;
+    const unsigned long long t_b = PHASE_NOW();
     const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+    const unsigned long long t_c = PHASE_NOW();
+    (void)t_b;
+    (void)t_c;
+#ifdef STCSP_PHASES
+    // everything after process_node (child stores / commit / candidate) is charged to "commit"
+    struct PhaseEnd {
+        const Ctx &c; int gw, lane; unsigned long long ta, tb, tc;
+        __device__ ~PhaseEnd() {
+            if (lane == 0) {
+                const unsigned long long td = PHASE_NOW();
+                add_stats(c, gw, ST_CYC_LOAD, tb - ta);
+                add_stats(c, gw, ST_CYC_CLASSIFY, tc - tb);  // whole process_node (incl. sweeps + wavefront revisions)
+                add_stats(c, gw, ST_CYC_COMMIT, td - tc);
+                add_stats(c, gw, ST_CYC_TOTAL, td - ta);
+            }
+        }
+    } phase_end{c, gw, lane, t_a, t_b, t_c};
+#endif
     if (oc == OC_FAIL) return;
     uint32_t *out_region = a.out_base + (size_t)ro * a.out_cap * c.NS;
     if (oc == OC_BRANCH) {

@@ -459,8 +459,6 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                             const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
-    const unsigned long long t_start = PHASE_NOW();
-    (void)t_start;
     const int set = hd.set;
     const uint32_t seed = hd.seed, expire = hd.expire;
     SetDesc S;
@@ -473,8 +471,6 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     // through an LDS copy (a Jacobi sweep); the remaining items are revised by the whole
     // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
     WaveStats ws;
-    const unsigned long long t_loaded = PHASE_NOW();
-    (void)t_loaded;
     int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
     uint32_t dirtyw = 0;
     if (lane < S.iw) {
@@ -633,13 +629,10 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_SWEEPS, ws.sweeps);
         add_stats(c, gw, ST_SKIPPED, ws.skipped);
 #ifdef STCSP_PHASES
-        add_stats(c, gw, ST_CYC_LOAD, t_loaded - t_start);
         add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
         add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
 #endif
     }
-    const unsigned long long t_prop = PHASE_NOW();
-    (void)t_prop;
     if (!consistent) {
         if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
         return OC_FAIL;

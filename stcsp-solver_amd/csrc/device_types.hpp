@@ -83,7 +83,7 @@ struct ItemDesc {
     int32_t idx[4];       // block word indices p*N+v.  NEXT: idx[0] = (p,X), idx[1] = (p+1,Y)
     int32_t toff;         // IT_SMALL: into tables[], one 32-bit row per tuple of variables 1..3
     int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2
-    int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal
+    int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal ; SMALL: number of table rows
 };
 
 struct SetDesc {          // one constraint set (entry of Solver::seenConstraints)

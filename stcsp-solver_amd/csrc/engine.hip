@@ -735,9 +735,9 @@ struct stcsp_engine {
                     (unsigned long long)tot[ST_POLLS], (unsigned long long)tot[ST_WAVES_WORKED], tot[ST_IDLE_CYC] / 1e6, tot[ST_BUSY_CYC] / 1e6);
 #ifdef STCSP_PHASES
         if (tot[ST_NODES])
-            fprintf(stderr, "[phases] cycles/node: load %.0f sweep %.0f wave %.0f classify+emit %.0f commit %.0f total %.0f (nodes %llu)\n",
-                    (double)tot[ST_CYC_LOAD] / tot[ST_NODES], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES], (double)tot[ST_CYC_WAVE] / tot[ST_NODES],
-                    (double)tot[ST_CYC_CLASSIFY] / tot[ST_NODES], (double)tot[ST_CYC_COMMIT] / tot[ST_NODES],
+            fprintf(stderr, "[phases] cycles/node: node load %.0f | process_node %.0f (of which sweeps %.0f, wavefront revisions %.0f) | emit/commit %.0f | total %.0f (nodes %llu)\n",
+                    (double)tot[ST_CYC_LOAD] / tot[ST_NODES], (double)tot[ST_CYC_CLASSIFY] / tot[ST_NODES], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES],
+                    (double)tot[ST_CYC_WAVE] / tot[ST_NODES], (double)tot[ST_CYC_COMMIT] / tot[ST_NODES],
                     (double)tot[ST_CYC_TOTAL] / tot[ST_NODES], (unsigned long long)tot[ST_NODES]);
 #endif
         ctr.levels = levels;
