@@ -186,6 +186,35 @@ int stcsp_engine_solve(stcsp_engine *engine, stcsp_result *result);
  * STCSP_F_NO_EXPORT, or per shard in sharded mode). */
 int stcsp_engine_export(stcsp_engine *engine, stcsp_result *result);
 
+/* ---- post-search graph passes on the device -------------------
+ * Run on the compacted automaton that the last solve()/export() left in HBM; the edge indices of
+ * the returned flags are those of that stcsp_result. Replaces, in this order,
+ *   graphTraverse         src/graph.cpp:357-418 (called at src/solveralgorithm.cpp:974)   always
+ *   adversarialTraverse   src/graph.cpp:304-355 (-a, solveralgorithm.cpp:975-978); the reference
+ *                         hard-codes variable index 5 (graph.cpp:329)
+ *   adversarialTraverse2  src/graph.cpp:247-302 (-z, solveralgorithm.cpp:980-983); the reference
+ *                         hard-codes opponent 5 / avatar 6 (graph.cpp:275)
+ * Unsharded engines only (sharded runs post-process the merged automaton on the host). */
+typedef struct stcsp_post_options {
+    int32_t adversarial_var;  /* variable index for adversarialTraverse, -1 = pass not run          */
+    int32_t adversarial2_op;  /* opponent variable for adversarialTraverse2, -1 = pass not run      */
+    int32_t adversarial2_ava; /* avatar variable                                                    */
+    int32_t reserved;
+} stcsp_post_options;
+
+typedef struct stcsp_post_result {
+    int64_t n_states, n_edges;  /* sizes of the arrays below (== the exported stcsp_result)          */
+    const uint8_t *state_valid; /* [n_states] Vertex::valid after the passes                         */
+    const uint8_t *state_final; /* [n_states] Vertex::final                                          */
+    const uint8_t *edge_alive;  /* [n_edges] 0 = the reference removed this edge from its EdgeMap    */
+    int32_t adver1, adver2;     /* what the reference prints as "adver1: %d; " / "adver2: %d" (the
+                                   root's valid flag after the pass), -1 when the pass was not run   */
+    int32_t rounds[3];          /* sweeps until the fixpoint: traverse, adversarial, adversarial2    */
+    double seconds;             /* wall time of the passes incl. copying the flags out               */
+} stcsp_post_result;
+
+int stcsp_engine_postprocess(stcsp_engine *engine, const stcsp_post_options *options, stcsp_post_result *out);
+
 void stcsp_engine_destroy(stcsp_engine *engine);
 
 /* Message of the last error on this engine (or of the last failed create when engine==NULL). */

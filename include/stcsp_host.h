@@ -54,6 +54,13 @@ int stcsp_automaton_traverse(stcsp_automaton *a);
 int stcsp_automaton_adversarial(stcsp_automaton *a, int var_index);
 /* adversarialTraverse2 (src/graph.cpp:247-302); the reference hard-codes opponent=5, avatar=6. */
 int stcsp_automaton_adversarial2(stcsp_automaton *a, int opponent_index, int avatar_index);
+/* Take the flags computed on the device by stcsp_engine_postprocess() (stcsp_engine.h) instead of
+ * running the three passes above on the host: valid / final per state, alive per edge, indexed like
+ * the stcsp_result the automaton was built from. */
+int stcsp_automaton_import_flags(stcsp_automaton *a, const uint8_t *state_valid, const uint8_t *state_final,
+                                 const uint8_t *edge_alive);
+/* Read the current flags back (any pointer may be NULL): [n_states], [n_states], [n_edges]. */
+int stcsp_automaton_flags(const stcsp_automaton *a, uint8_t *state_valid, uint8_t *state_final, uint8_t *edge_alive);
 /* renumberVertex (src/graph.cpp:420-442). */
 int stcsp_automaton_renumber(stcsp_automaton *a);
 

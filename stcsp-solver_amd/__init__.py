@@ -70,6 +70,18 @@ class Result(C.Structure):
                 ("counters", Counters)]
 
 
+class PostOptions(C.Structure):
+    _fields_ = [("adversarial_var", C.c_int32), ("adversarial2_op", C.c_int32), ("adversarial2_ava", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class PostResult(C.Structure):
+    _fields_ = [("n_states", C.c_int64), ("n_edges", C.c_int64),
+                ("state_valid", C.POINTER(C.c_uint8)), ("state_final", C.POINTER(C.c_uint8)),
+                ("edge_alive", C.POINTER(C.c_uint8)),
+                ("adver1", C.c_int32), ("adver2", C.c_int32), ("rounds", C.c_int32 * 3), ("seconds", C.c_double)]
+
+
 F_KEEP_RAW_EDGES = 1
 F_NO_EXPORT = 2
 F_PROFILE = 4
@@ -79,13 +91,14 @@ ENGINE_SYMBOLS = [
     "stcsp_engine_create", "stcsp_engine_solve", "stcsp_engine_export", "stcsp_engine_destroy",
     "stcsp_engine_last_error", "stcsp_engine_begin", "stcsp_engine_expand_local",
     "stcsp_engine_candidate_bytes", "stcsp_engine_outbox", "stcsp_engine_commit", "stcsp_engine_finish",
-    "stcsp_engine_counters", "stcsp_engine_sets_blob", "stcsp_engine_sets_import",
+    "stcsp_engine_counters", "stcsp_engine_sets_blob", "stcsp_engine_sets_import", "stcsp_engine_postprocess",
 ]
 HOST_SYMBOLS = [
     "stcsp_model_load_file", "stcsp_model_load_text", "stcsp_model_problem", "stcsp_model_free",
     "stcsp_host_last_error", "stcsp_model_constraint_string",
     "stcsp_automaton_build", "stcsp_automaton_free", "stcsp_automaton_traverse",
     "stcsp_automaton_adversarial", "stcsp_automaton_adversarial2", "stcsp_automaton_renumber",
+    "stcsp_automaton_import_flags", "stcsp_automaton_flags",
     "stcsp_automaton_write_dot", "stcsp_automaton_canonical", "stcsp_automaton_num_states",
     "stcsp_automaton_num_live_states", "stcsp_automaton_num_live_edges",
     "stcsp_merge_shards", "stcsp_merged_result", "stcsp_merged_free", "stcsp_host_free",
@@ -136,6 +149,8 @@ def host_lib() -> C.CDLL:
         lib.stcsp_automaton_adversarial.argtypes = [C.c_void_p, C.c_int]
         lib.stcsp_automaton_adversarial2.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.stcsp_automaton_renumber.argtypes = [C.c_void_p]
+        lib.stcsp_automaton_import_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.stcsp_automaton_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.stcsp_automaton_write_dot.argtypes = [C.c_void_p, C.c_char_p]
         lib.stcsp_automaton_canonical.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         lib.stcsp_automaton_canonical.restype = C.c_void_p
@@ -176,6 +191,8 @@ def bind_engine_api(lib: C.CDLL, prefix: str = "stcsp_engine") -> None:
         g("counters").argtypes = [C.c_void_p, C.POINTER(Counters)]
         g("sets_blob").argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64)]
         g("sets_import").argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]
+    if hasattr(lib, f"{prefix}_postprocess"):
+        g("postprocess").argtypes = [C.c_void_p, C.POINTER(PostOptions), C.POINTER(PostResult)]
 
 
 def hip_lib() -> C.CDLL:
@@ -258,6 +275,7 @@ class Automaton:
             raise StcspError(rc, "automaton build failed")
         self._h = h
         self._model = model
+        self._n_edges = result.n_edges
 
     def traverse(self):
         host_lib().stcsp_automaton_traverse(self._h)
@@ -272,6 +290,22 @@ class Automaton:
     def renumber(self):
         host_lib().stcsp_automaton_renumber(self._h)
         return self
+
+    def import_flags(self, post: "PostResult"):
+        """Adopt the flags of Engine.postprocess() (device passes) instead of traverse()/adversarial*()."""
+        rc = host_lib().stcsp_automaton_import_flags(self._h, post.state_valid, post.state_final, post.edge_alive)
+        if rc != 0:
+            raise StcspError(rc, "import_flags failed")
+        return self
+
+    def flags(self):
+        """(valid, final, alive) as bytes objects."""
+        lib = host_lib()
+        ns = lib.stcsp_automaton_num_states(self._h)
+        ne = self._n_edges
+        v, f, a = C.create_string_buffer(max(ns, 1)), C.create_string_buffer(max(ns, 1)), C.create_string_buffer(max(ne, 1))
+        lib.stcsp_automaton_flags(self._h, v, f, a)
+        return v.raw[:ns], f.raw[:ns], a.raw[:ne]
 
     def write_dot(self, path: str):
         rc = host_lib().stcsp_automaton_write_dot(self._h, os.fsencode(path))
@@ -398,6 +432,13 @@ class EngineBase:
     def sets_import(self, words):
         arr = (C.c_int32 * len(words))(*words)
         self._check(self._f("sets_import")(self._h, arr, len(words)))
+
+    def postprocess(self, adversarial: int = -1, adversarial2: tuple | None = None) -> PostResult:
+        """graphTraverse [+ adversarialTraverse(var)] [+ adversarialTraverse2(op, ava)] on the device."""
+        po = PostOptions(adversarial, adversarial2[0] if adversarial2 else -1, adversarial2[1] if adversarial2 else -1, 0)
+        out = PostResult()
+        self._check(self._f("postprocess")(self._h, C.byref(po), C.byref(out)))
+        return out
 
     def automaton(self, result: Result | None = None) -> Automaton:
         return Automaton(self._model, result if result is not None else self.result)

@@ -50,6 +50,7 @@
 using namespace stcsp;
 
 #include "dev_kernels.hpp"
+#include "dev_postproc.hpp"
 
 using namespace stcsp::dev;
 
@@ -139,6 +140,12 @@ struct stcsp_engine {
     uint32_t *h_keys = nullptr;
     uint8_t *h_fail = nullptr;
     size_t h_edge_cap = 0, h_state_cap = 0;
+    // device post-processing (dev_postproc.hpp) over the compacted export
+    bool exp_on_device = false;  // d_osrc/d_odst/d_oval/d_state_keys describe the last exported automaton
+    size_t exp_edges = 0;
+    DevBuf<uint8_t> d_pvalid, d_pfinal, d_palive, d_pnodeok;
+    DevBuf<uint32_t> d_pcover;
+    std::vector<uint8_t> p_valid, p_final, p_alive;
 
     ~stcsp_engine() {
         for (auto &e : ev_pool) {
@@ -449,6 +456,7 @@ struct stcsp_engine {
         truncated = false;
         levels = 0;
         finished = false;
+        exp_on_device = false;
         ev_used = 0;
         seconds_expand_kernel = 0;
         expand_launches = 0;
@@ -836,6 +844,120 @@ struct stcsp_engine {
         return read_plan();
     }
 
+    // graphTraverse / adversarialTraverse / adversarialTraverse2 on the device (dev_postproc.hpp)
+    int postprocess(const stcsp_post_options *po, stcsp_post_result *out) {
+        if (opt.world != 1) return fail(STCSP_E_STATE, "device post-processing is for unsharded engines (merge shards on the host)");
+        if (!exp_on_device) return fail(STCSP_E_STATE, "postprocess needs the device export of a finished solve (export first)");
+        const int N = ctx.N;
+        const int a1 = po ? po->adversarial_var : -1, op = po ? po->adversarial2_op : -1, ava = po ? po->adversarial2_ava : -1;
+        if (a1 >= N || op >= N || ava >= N || a1 < -1 || op < -1 || (op >= 0 && ava < 0))
+            return fail(STCSP_E_INVALID, "postprocess: variable index out of range");
+        auto t0 = std::chrono::steady_clock::now();
+        const size_t E = exp_edges;
+        const uint32_t S = n_states;
+        auto width = [&](int v) { return mgr.ub[v] - mgr.lb[v] + 1; };
+        auto full_mask = [&](int v) { return width(v) >= 32 ? 0xffffffffu : ((1u << width(v)) - 1u); };
+        const int wa = op >= 0 ? width(ava) : 0;
+        if (d_pvalid.n < S) {
+            const size_t cap = (size_t)S + S / 4 + 256;
+            HIPCHK(d_pvalid.alloc(cap));
+            HIPCHK(d_pfinal.alloc(cap));
+            HIPCHK(d_pnodeok.alloc(cap));
+        }
+        const size_t cover_words = (size_t)S * std::max(1, wa);
+        if (d_pcover.n < cover_words) HIPCHK(d_pcover.alloc(cover_words + cover_words / 4 + 256));
+        if (d_palive.n < E + 1) HIPCHK(d_palive.alloc(E + E / 4 + 256));
+        if (!d_post.p) HIPCHK(d_post.alloc(4));
+        const unsigned eb = (unsigned)((E + 255) / 256), sb = (S + 255) / 256;
+        const long long *src = d_osrc.p, *dst = d_odst.p;
+        const int32_t *val = d_oval.p;
+        uint32_t *changed = d_post.p;
+        // one round = the kernels `body` enqueues; returns the number of rounds until nothing changed
+        auto fixpoint = [&](int &rounds, auto body) -> int {  // HIPCHK returns the error code from the enclosing lambda
+            for (rounds = 0;; rounds++) {
+                HIPCHK(hipMemsetAsync(changed, 0, sizeof(uint32_t), stream));
+                const int rb = body();
+                if (rb != STCSP_OK) return rb;
+                uint32_t ch = 0;
+                HIPCHK(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                if (!ch) return STCSP_OK;
+                if (rounds > (int)S + 8) return fail(STCSP_E_INTERNAL, "post-processing fixpoint did not converge");
+            }
+        };
+        int rounds[3] = {0, 0, 0};
+        HIPCHK(hipMemsetAsync(d_palive.p, 1, E + 1, stream));
+        // graphTraverse (src/graph.cpp:357-418); the loop bound numSignVar + numUntil is the reference's
+        hipLaunchKernelGGL(k_trav_init, dim3(sb), dim3(256), 0, stream, S, (const uint32_t *)d_state_keys.p, ctx.KL, mgr.n_sig,
+                           mgr.n_sig + mgr.n_until, (int)(mgr.n_until_cons == 0), d_pvalid.p, d_pfinal.p);
+        if (E) {
+            int rc = fixpoint(rounds[0], [&] {
+                hipLaunchKernelGGL(k_trav_back, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, (const uint8_t *)d_palive.p, d_pvalid.p, changed);
+                return (int)STCSP_OK;
+            });
+            if (rc != STCSP_OK) return rc;
+            hipLaunchKernelGGL(k_kill_into_invalid, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, d_palive.p, (const uint8_t *)d_pvalid.p, 1);
+        }
+        int adver1 = -1, adver2 = -1;
+        uint8_t root_valid = 0;
+        if (a1 >= 0) {  // adversarialTraverse (src/graph.cpp:304-355)
+            const uint32_t full = full_mask(a1);
+            int rc = fixpoint(rounds[1], [&] {
+                HIPCHK(hipMemsetAsync(d_pcover.p, 0, (size_t)S * sizeof(uint32_t), stream));
+                if (E)
+                    hipLaunchKernelGGL(k_adv_cover, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, val, N, a1, mgr.lb[a1],
+                                       (const uint8_t *)d_palive.p, (const uint8_t *)d_pvalid.p, d_pcover.p);
+                hipLaunchKernelGGL(k_adv_check, dim3(sb), dim3(256), 0, stream, S, (const uint32_t *)d_pcover.p, full, d_pvalid.p, changed);
+                return (int)STCSP_OK;
+            });
+            if (rc != STCSP_OK) return rc;
+            if (E) hipLaunchKernelGGL(k_kill_into_invalid, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, d_palive.p, (const uint8_t *)d_pvalid.p, 0);
+            HIPCHK(hipMemcpyAsync(&root_valid, d_pvalid.p, 1, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            adver1 = root_valid;
+        }
+        if (op >= 0) {  // adversarialTraverse2 (src/graph.cpp:247-302)
+            const uint32_t full = full_mask(op);
+            int rc = fixpoint(rounds[2], [&] {
+                HIPCHK(hipMemsetAsync(d_pcover.p, 0, cover_words * sizeof(uint32_t), stream));
+                if (E)
+                    hipLaunchKernelGGL(k_adv2_cover, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, val, N, op, ava, mgr.lb[op], mgr.lb[ava],
+                                       wa, (const uint8_t *)d_palive.p, (const uint8_t *)d_pvalid.p, d_pcover.p);
+                hipLaunchKernelGGL(k_adv2_check, dim3(sb), dim3(256), 0, stream, S, (const uint32_t *)d_pcover.p, wa, full, d_pvalid.p, d_pnodeok.p, changed);
+                if (E)
+                    hipLaunchKernelGGL(k_adv2_kill, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, val, N, ava, mgr.lb[ava], wa, full, d_palive.p,
+                                       (const uint8_t *)d_pvalid.p, (const uint8_t *)d_pnodeok.p, (const uint32_t *)d_pcover.p);
+                return (int)STCSP_OK;
+            });
+            if (rc != STCSP_OK) return rc;
+            HIPCHK(hipMemcpyAsync(&root_valid, d_pvalid.p, 1, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            adver2 = root_valid;
+            // the reference drops the edges into invalid states only when the root survived (graph.cpp:288-301)
+            if (root_valid && E)
+                hipLaunchKernelGGL(k_kill_into_invalid, dim3(eb), dim3(256), 0, stream, (uint32_t)E, src, dst, d_palive.p, (const uint8_t *)d_pvalid.p, 0);
+        }
+        HIPCHK(hipGetLastError());
+        p_valid.resize(S);
+        p_final.resize(S);
+        p_alive.resize(E + 1);
+        HIPCHK(hipMemcpyAsync(p_valid.data(), d_pvalid.p, S, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(p_final.data(), d_pfinal.p, S, hipMemcpyDeviceToHost, stream));
+        if (E) HIPCHK(hipMemcpyAsync(p_alive.data(), d_palive.p, E, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        memset(out, 0, sizeof *out);
+        out->n_states = S;
+        out->n_edges = (int64_t)E;
+        out->state_valid = p_valid.data();
+        out->state_final = p_final.data();
+        out->edge_alive = p_alive.data();
+        out->adver1 = adver1;
+        out->adver2 = adver2;
+        for (int i = 0; i < 3; i++) out->rounds[i] = rounds[i];
+        out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return STCSP_OK;
+    }
+
     // unsharded export: ok-fixpoint + compaction on the device, result arrays land in pinned memory
     int export_device(stcsp_result *res, stcsp_counters &ctr, size_t &E_out) {
         const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N;
@@ -938,6 +1060,8 @@ struct stcsp_engine {
         res->edge_dst = (const int64_t *)h_odst;
         res->edge_values = h_oval;
         E_out = live;
+        exp_edges = live;
+        exp_on_device = true;
         return STCSP_OK;
     }
 
@@ -1093,6 +1217,11 @@ int stcsp_engine_export(stcsp_engine *e, stcsp_result *result) {
     if (!e || !result) return STCSP_E_INVALID;
     if (!e->begun) return e->fail(STCSP_E_STATE, "export before a solve");
     return e->export_result(result);
+}
+
+int stcsp_engine_postprocess(stcsp_engine *e, const stcsp_post_options *options, stcsp_post_result *out) {
+    if (!e || !out) return STCSP_E_INVALID;
+    return e->postprocess(options, out);
 }
 
 void stcsp_engine_destroy(stcsp_engine *e) { delete e; }

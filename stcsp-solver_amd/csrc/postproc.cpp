@@ -388,6 +388,22 @@ int stcsp_automaton_traverse(stcsp_automaton *a) {
 }
 int stcsp_automaton_adversarial(stcsp_automaton *a, int var_index) { return a ? a->a.adversarial(var_index) : STCSP_E_INVALID; }
 int stcsp_automaton_adversarial2(stcsp_automaton *a, int op, int ava) { return a ? a->a.adversarial2(op, ava) : STCSP_E_INVALID; }
+int stcsp_automaton_import_flags(stcsp_automaton *a, const uint8_t *valid, const uint8_t *final_flags, const uint8_t *alive) {
+    if (!a || !valid || !final_flags || (!alive && !a->a.esrc.empty())) return STCSP_E_INVALID;
+    Automaton &g = a->a;
+    g.valid.assign(valid, valid + g.n_states);
+    g.final_.assign(final_flags, final_flags + g.n_states);
+    for (size_t e = 0; e < g.esrc.size(); e++) g.ealive[e] = g.ealive[e] && alive[e];
+    return STCSP_OK;
+}
+int stcsp_automaton_flags(const stcsp_automaton *a, uint8_t *valid, uint8_t *final_flags, uint8_t *alive) {
+    if (!a) return STCSP_E_INVALID;
+    const Automaton &g = a->a;
+    if (valid) memcpy(valid, g.valid.data(), g.valid.size());
+    if (final_flags) memcpy(final_flags, g.final_.data(), g.final_.size());
+    if (alive) memcpy(alive, g.ealive.data(), g.ealive.size());
+    return STCSP_OK;
+}
 int stcsp_automaton_renumber(stcsp_automaton *a) {
     if (!a) return STCSP_E_INVALID;
     a->a.renumber();

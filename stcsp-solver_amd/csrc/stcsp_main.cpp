@@ -68,9 +68,18 @@ static int run_once(const Flags &f, bool print_line, double *total) {
     double t_proc = cpu_time();
     stcsp_automaton *a = nullptr;
     stcsp_automaton_build(p, &res, &a);
-    stcsp_automaton_traverse(a);                                             // solveralgorithm.cpp:974
-    if (f.adv1) printf("adver1: %d; ", stcsp_automaton_adversarial(a, 5));   // :975-978
-    if (f.adv2) printf("adver2: %d\n", stcsp_automaton_adversarial2(a, 5, 6)); // :980-983
+    // graphTraverse / adversarialTraverse / adversarialTraverse2 (solveralgorithm.cpp:974-983) run on
+    // the device over the automaton the export left in HBM; the host only adopts the flags
+    stcsp_post_options po = {f.adv1 ? 5 : -1, f.adv2 ? 5 : -1, f.adv2 ? 6 : -1, 0};
+    stcsp_post_result post;
+    rc = stcsp_engine_postprocess(eng, &po, &post);
+    if (rc != STCSP_OK) {
+        fprintf(stderr, "%s\n", stcsp_engine_last_error(eng));
+        return 1;
+    }
+    stcsp_automaton_import_flags(a, post.state_valid, post.state_final, post.edge_alive);
+    if (f.adv1) printf("adver1: %d; ", post.adver1);
+    if (f.adv2) printf("adver2: %d\n", post.adver2);
     stcsp_automaton_renumber(a);
     double proc_time = cpu_time() - t_proc;
     if (f.print_solution) stcsp_automaton_write_dot(a, "solutions.dot");

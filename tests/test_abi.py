@@ -47,3 +47,24 @@ def test_abi_struct_sizes(stcsp):
     assert C.sizeof(stcsp.Node) == 24
     assert C.sizeof(stcsp.Options) == 40
     assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 24
+    assert C.sizeof(stcsp.PostOptions) == 16
+    assert C.sizeof(stcsp.PostResult) == 72
+
+
+def test_automaton_flags_roundtrip(stcsp, RefOracle):
+    """stcsp_automaton_import_flags / stcsp_automaton_flags (the hand-over point of the device
+    post-processing) on the host: flags exported from one automaton reproduce it in another."""
+    m = stcsp.Model(text="var x:[0,1]; var y:[0,1]; x until y;")
+    o = RefOracle(m)
+    r = o.solve()
+    a = o.automaton(r)
+    a.traverse()
+    valid, final, alive = a.flags()
+    assert len(valid) == r.n_states and len(alive) == r.n_edges
+
+    class P:  # shaped like PostResult
+        state_valid, state_final, edge_alive = valid, final, alive
+
+    b = o.automaton(r).import_flags(P)
+    assert b.flags() == (valid, final, alive)
+    assert a.renumber().canonical() == b.renumber().canonical()
