@@ -69,6 +69,13 @@ int stcsp_automaton_renumber(stcsp_automaton *a);
  * __gnu_cxx::hash_map iteration order: SURVEY.md parity level L3, not a goal). */
 int stcsp_automaton_write_dot(const stcsp_automaton *a, const char *path);
 
+/* Compact binary form of the same printed automaton (layout: postproc.cpp, "STCSPAUT" v1):
+ * ~(4 + n_vars) bytes per edge instead of ~4*n_vars of text -- the exchange format for consumers
+ * that do not need Graphviz. read_binary gives an automaton on which write_dot / canonical /
+ * num_* work (traverse / adversarial passes have already been applied to what it holds). */
+int stcsp_automaton_write_binary(const stcsp_automaton *a, const char *path);
+int stcsp_automaton_read_binary(const char *path, stcsp_automaton **out);
+
 /* Canonical text of the automaton: BFS from the root over edges
  * sorted by label, states renumbered in discovery order, constraint-set ids renumbered by
  * first appearance. sha256 of this text is the parity object. malloc'd; stcsp_host_free. */

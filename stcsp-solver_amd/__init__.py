@@ -98,7 +98,7 @@ HOST_SYMBOLS = [
     "stcsp_host_last_error", "stcsp_model_constraint_string",
     "stcsp_automaton_build", "stcsp_automaton_free", "stcsp_automaton_traverse",
     "stcsp_automaton_adversarial", "stcsp_automaton_adversarial2", "stcsp_automaton_renumber",
-    "stcsp_automaton_import_flags", "stcsp_automaton_flags",
+    "stcsp_automaton_import_flags", "stcsp_automaton_flags", "stcsp_automaton_write_binary", "stcsp_automaton_read_binary",
     "stcsp_automaton_write_dot", "stcsp_automaton_canonical", "stcsp_automaton_num_states",
     "stcsp_automaton_num_live_states", "stcsp_automaton_num_live_edges",
     "stcsp_merge_shards", "stcsp_merged_result", "stcsp_merged_free", "stcsp_host_free",
@@ -152,6 +152,8 @@ def host_lib() -> C.CDLL:
         lib.stcsp_automaton_import_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.stcsp_automaton_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.stcsp_automaton_write_dot.argtypes = [C.c_void_p, C.c_char_p]
+        lib.stcsp_automaton_write_binary.argtypes = [C.c_void_p, C.c_char_p]
+        lib.stcsp_automaton_read_binary.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.stcsp_automaton_canonical.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         lib.stcsp_automaton_canonical.restype = C.c_void_p
         for f in ("stcsp_automaton_num_states", "stcsp_automaton_num_live_states", "stcsp_automaton_num_live_edges"):
@@ -311,6 +313,21 @@ class Automaton:
         rc = host_lib().stcsp_automaton_write_dot(self._h, os.fsencode(path))
         if rc != 0:
             raise StcspError(rc, f"cannot write {path}")
+
+    def write_binary(self, path: str):
+        rc = host_lib().stcsp_automaton_write_binary(self._h, os.fsencode(path))
+        if rc != 0:
+            raise StcspError(rc, f"cannot write {path}")
+
+    @classmethod
+    def read_binary(cls, path: str) -> "Automaton":
+        h = C.c_void_p()
+        rc = host_lib().stcsp_automaton_read_binary(os.fsencode(path), C.byref(h))
+        if rc != 0:
+            raise StcspError(rc, f"cannot read {path}")
+        a = cls.__new__(cls)
+        a._h, a._model, a._n_edges = h, None, 0
+        return a
 
     def canonical(self) -> str:
         lib = host_lib()

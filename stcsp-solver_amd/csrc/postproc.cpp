@@ -25,12 +25,63 @@
 
 namespace stcsp {
 
+// Append-only text buffer with hand-rolled integer formatting: the reference prints one fprintf
+// per edge (src/graph.cpp:92-101; 82 MB of text on partialorder_14), which dominates the wall
+// time once the search itself takes milliseconds.
+struct TextOut {
+    std::vector<char> buf;
+    size_t n = 0;
+    FILE *fp = nullptr;  // nullptr: keep everything in memory
+    explicit TextOut(FILE *f = nullptr, size_t cap = 1u << 22) : buf(cap), fp(f) {}
+    void room(size_t need) {
+        if (n + need <= buf.size()) return;
+        if (fp) {
+            fwrite(buf.data(), 1, n, fp);
+            n = 0;
+            if (need > buf.size()) buf.resize(need * 2);
+        } else {
+            buf.resize(std::max(buf.size() * 2, n + need));
+        }
+    }
+    void str(const char *s, size_t len) {
+        room(len);
+        memcpy(buf.data() + n, s, len);
+        n += len;
+    }
+    void str(const std::string &s) { str(s.data(), s.size()); }
+    void lit(const char *s) { str(s, strlen(s)); }
+    void ch(char c) {
+        room(1);
+        buf[n++] = c;
+    }
+    void num(long long v) {
+        room(24);
+        char tmp[24];
+        int k = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do {
+            tmp[k++] = (char)('0' + u % 10);
+            u /= 10;
+        } while (u);
+        if (v < 0) buf[n++] = '-';
+        while (k) buf[n++] = tmp[--k];
+    }
+    void flush() {
+        if (fp && n) {
+            fwrite(buf.data(), 1, n, fp);
+            n = 0;
+        }
+    }
+    std::string take() { return std::string(buf.data(), n); }
+};
+
 struct Automaton {
     int n_vars = 0, sig_len = 0, n_sig_vars = 0, n_until = 0;
     std::vector<std::string> names;
     std::vector<uint8_t> is_sig;
     std::vector<int> var_lb, var_ub;
     int64_t n_states = 0;
+    int64_t table_states = -1;  // "# Number of nodes" when it differs from n_states (binary reload)
     std::vector<int32_t> cid, sig;
     std::vector<uint8_t> fail, valid, final_;
     std::vector<int64_t> id;  // printed vertex id (renumberVertex)
@@ -217,14 +268,111 @@ struct Automaton {
         return s;
     }
 
+    // label text of one edge ("v0, v1, ..., vN-1"): per variable the text of every domain value
+    // is formatted once, then an edge label is a run of short copies
+    struct LabelTable {
+        // Consecutive variables are grouped while the product of their domain sizes stays small
+        // and the joint text fits 16 bytes; a group's text is one table lookup + one 16-byte copy
+        // (partialorder_14: 31 values per label -> 8 copies).
+        struct Piece {
+            char text[16];
+            uint32_t len;
+        };
+        struct Group {
+            int first, count;  // variables [first, first + count)
+            int base;          // index of the group's first piece
+            int combos;
+        };
+        std::vector<Piece> piece;
+        std::vector<Group> groups;
+        const Automaton &a;
+        const char *sep;
+        LabelTable(const Automaton &au, const char *sep_) : a(au), sep(sep_) {
+            const size_t seplen = strlen(sep);
+            auto width = [&](int i) { return (long long)a.var_ub[i] - a.var_lb[i] + 1; };
+            auto maxlen = [&](int i) {
+                return std::max(std::to_string(a.var_lb[i]).size(), std::to_string(a.var_ub[i]).size()) + (i != a.n_vars - 1 ? seplen : 0);
+            };
+            for (int i = 0; i < a.n_vars;) {
+                Group g{i, 0, (int)piece.size(), 1};
+                size_t len = 0;
+                while (i < a.n_vars && width(i) <= 4096 && (long long)g.combos * width(i) <= 4096 && len + maxlen(i) <= sizeof(Piece::text)) {
+                    g.combos *= (int)width(i);
+                    len += maxlen(i);
+                    g.count++;
+                    i++;
+                }
+                if (g.count == 0) {  // a variable that does not fit a table: formatted directly
+                    g.count = -1;
+                    i++;
+                    groups.push_back(g);
+                    continue;
+                }
+                for (int c = 0; c < g.combos; c++) {  // mixed radix, first variable most significant
+                    std::string t;
+                    int rem = c, div = g.combos;
+                    for (int k = 0; k < g.count; k++) {
+                        const int v = g.first + k;
+                        div /= (int)width(v);
+                        t += std::to_string(a.var_lb[v] + rem / div);
+                        rem %= div;
+                        if (v != a.n_vars - 1) t += sep;
+                    }
+                    Piece pc{};
+                    memcpy(pc.text, t.data(), t.size());
+                    pc.len = (uint32_t)t.size();
+                    piece.push_back(pc);
+                }
+                groups.push_back(g);
+            }
+        }
+        void put(TextOut &o, int64_t e) const {
+            const int32_t *row = &a.eval[e * a.n_vars];
+            o.room((size_t)a.n_vars * 16 + 32);
+            char *w = o.buf.data() + o.n;
+            for (const Group &g : groups) {
+                bool direct = g.count < 0;
+                int idx = 0;
+                if (!direct)
+                    for (int k = 0; k < g.count; k++) {
+                        const int v = g.first + k;
+                        const int d = row[v] - a.var_lb[v], wd = a.var_ub[v] - a.var_lb[v] + 1;
+                        direct |= (d < 0) | (d >= wd);  // value outside the declared bounds
+                        idx = idx * wd + d;
+                    }
+                if (!direct) {
+                    const Piece &pc = piece[g.base + idx];
+                    memcpy(w, pc.text, sizeof pc.text);
+                    w += pc.len;
+                    continue;
+                }
+                o.n = (size_t)(w - o.buf.data());
+                const int cnt = g.count < 0 ? 1 : g.count;
+                for (int k = 0; k < cnt; k++) {
+                    o.num(row[g.first + k]);
+                    if (g.first + k != a.n_vars - 1) o.lit(sep);
+                }
+                o.room((size_t)a.n_vars * 16 + 32);
+                w = o.buf.data() + o.n;
+            }
+            o.n = (size_t)(w - o.buf.data());
+        }
+    };
+
     // solverOut / graphOut / vertexOut / edgeOut
     int write_dot(const char *path) const {
         FILE *fp = fopen(path, "w");
         if (!fp) return STCSP_E_INVALID;
-        fprintf(fp, "# Number of nodes = %lld\n", (long long)n_states);
-        fprintf(fp, "%s\n%s\n", name_line().c_str(), sig_name_line().c_str());
-        fprintf(fp, "digraph \"StCSP\" {\n");
+        TextOut o(fp);
+        o.lit("# Number of nodes = ");
+        o.num(table_states >= 0 ? table_states : n_states);
+        o.ch('\n');
+        o.str(name_line());
+        o.ch('\n');
+        o.str(sig_name_line());
+        o.lit("\ndigraph \"StCSP\" {\n");
         if (valid[0]) {
+            LabelTable labels(*this, ", ");
             std::vector<uint8_t> seen(n_states, 0);
             // iterative version of the reference's recursive vertexOut
             struct Frame {
@@ -233,12 +381,15 @@ struct Automaton {
             std::vector<Frame> st;
             auto open = [&](int64_t v) {
                 seen[v] = 1;
-                fprintf(fp, "%lld [shape=%s, label=\"%d: %s\"];\n", (long long)id[v], final_[v] ? "doublecircle" : "circle",
-                        cid[v], sig_text(v, ", ").c_str());
+                o.num(id[v]);
+                o.lit(final_[v] ? " [shape=doublecircle, label=\"" : " [shape=circle, label=\"");
+                o.num(cid[v]);
+                o.lit(": ");
+                o.str(sig_text(v, ", "));
+                o.lit("\"];\n");
                 st.push_back(Frame{v, out_off[v]});
             };
             open(0);
-            std::string line;
             while (!st.empty()) {
                 Frame &f = st.back();
                 while (f.k < out_off[f.v + 1] && !ealive[out_edge[f.k]]) f.k++;
@@ -250,77 +401,265 @@ struct Automaton {
                 int64_t v = f.v;
                 while (f.k < out_off[v + 1] && edst[out_edge[f.k]] == d) {  // one destination bucket
                     int64_t e = out_edge[f.k++];
-                    if (!ealive[e]) continue;
-                    line.clear();
-                    for (int i = 0; i < n_vars; i++) {
-                        line += std::to_string(eval[e * n_vars + i]);
-                        if (i != n_vars - 1) line += ", ";
+                    if (f.k + 6 < out_off[v + 1]) {  // label rows are visited in CSR order, i.e. at random
+                        const char *nx = (const char *)&eval[out_edge[f.k + 6] * n_vars];
+                        __builtin_prefetch(nx);
+                        __builtin_prefetch(nx + 64);
                     }
-                    fprintf(fp, "%lld -> %lld [label=\"%s\"];\n", (long long)id[v], (long long)id[d], line.c_str());
+                    if (!ealive[e]) continue;
+                    o.num(id[v]);
+                    o.lit(" -> ");
+                    o.num(id[d]);
+                    o.lit(" [label=\"");
+                    labels.put(o, e);
+                    o.lit("\"];\n");
                 }
                 if (!seen[d]) open(d);  // invalidates f
             }
         }
-        fprintf(fp, "}\n");
+        o.lit("}\n");
+        o.flush();
+        const bool bad = ferror(fp) != 0;
+        return (fclose(fp) != 0 || bad) ? STCSP_E_INVALID : STCSP_OK;
+    }
+
+    // ---- compact binary form of the printed automaton ----------
+    // Little-endian. Holds what solutions.dot holds -- the states reachable from a valid root over
+    // kept edges, with their printed ids -- at ~(4 + n_vars) bytes per edge instead of ~120 of text.
+    //   char  magic[8] = "STCSPAUT"; u32 version = 1; u32 n_vars, sig_len, n_sig_vars, n_until;
+    //   u32 value_bytes (1: u8 offset from the variable's lb, 4: i32); u64 table_states; u64 n_states; u64 n_edges;
+    //   per variable: i32 lb, i32 ub, u8 is_signature, u16 name_len, name
+    //   u32 id[n_states]; i32 cid[n_states]; u8 final[n_states]; i32 sig[n_states*sig_len]; u32 out_degree[n_states];
+    //   u32 dst[n_edges] (index into the state arrays, grouped by source in state order); values[n_edges*n_vars]
+    static constexpr const char *kMagic = "STCSPAUT";
+    int write_binary(const char *path) const {
+        FILE *fp = fopen(path, "wb");
+        if (!fp) return STCSP_E_INVALID;
+        std::vector<int64_t> order;  // kept states in discovery order (index 0 = root)
+        std::vector<int64_t> dense(n_states, -1);
+        if (valid[0]) {
+            dense[0] = 0;
+            order.push_back(0);
+            for (size_t q = 0; q < order.size(); q++)
+                for (int64_t k = out_off[order[q]]; k < out_off[order[q] + 1]; k++) {
+                    const int64_t e = out_edge[k];
+                    if (ealive[e] && dense[edst[e]] < 0) {
+                        dense[edst[e]] = (int64_t)order.size();
+                        order.push_back(edst[e]);
+                    }
+                }
+        }
+        bool narrow = true;
+        for (int i = 0; i < n_vars; i++) narrow = narrow && (long long)var_ub[i] - var_lb[i] < 256;
+        std::vector<uint32_t> ids, outdeg, dsts;
+        std::vector<int32_t> cids, sigs;
+        std::vector<uint8_t> fins, vals8;
+        std::vector<int32_t> vals32;
+        for (int64_t v : order) {
+            ids.push_back((uint32_t)id[v]);
+            cids.push_back(cid[v]);
+            fins.push_back(final_[v]);
+            for (int c = 0; c < sig_len; c++) sigs.push_back(sig[v * sig_len + c]);
+            uint32_t deg = 0;
+            for (int64_t k = out_off[v]; k < out_off[v + 1]; k++) {
+                const int64_t e = out_edge[k];
+                if (!ealive[e]) continue;
+                deg++;
+                dsts.push_back((uint32_t)dense[edst[e]]);
+                for (int i = 0; i < n_vars; i++) {
+                    const int32_t x = eval[e * n_vars + i];
+                    if (narrow && (x < var_lb[i] || x > var_ub[i])) {  // cannot happen for engine results
+                        fclose(fp);
+                        return STCSP_E_INVALID;
+                    }
+                    if (narrow) vals8.push_back((uint8_t)(x - var_lb[i]));
+                    else vals32.push_back(x);
+                }
+            }
+            outdeg.push_back(deg);
+        }
+        auto put = [&](const void *ptr, size_t bytes) { if (bytes) fwrite(ptr, 1, bytes, fp); };
+        auto u32 = [&](uint32_t x) { put(&x, 4); };
+        auto u64 = [&](uint64_t x) { put(&x, 8); };
+        put(kMagic, 8);
+        u32(1);
+        u32((uint32_t)n_vars);
+        u32((uint32_t)sig_len);
+        u32((uint32_t)n_sig_vars);
+        u32((uint32_t)n_until);
+        u32(narrow ? 1 : 4);
+        u64((uint64_t)n_states);
+        u64(order.size());
+        u64(dsts.size());
+        for (int i = 0; i < n_vars; i++) {
+            int32_t b[2] = {var_lb[i], var_ub[i]};
+            put(b, 8);
+            put(&is_sig[i], 1);
+            uint16_t nl = (uint16_t)names[i].size();
+            put(&nl, 2);
+            put(names[i].data(), nl);
+        }
+        put(ids.data(), ids.size() * 4);
+        put(cids.data(), cids.size() * 4);
+        put(fins.data(), fins.size());
+        put(sigs.data(), sigs.size() * 4);
+        put(outdeg.data(), outdeg.size() * 4);
+        put(dsts.data(), dsts.size() * 4);
+        if (narrow) put(vals8.data(), vals8.size());
+        else put(vals32.data(), vals32.size() * 4);
+        const bool bad = ferror(fp) != 0;
+        return (fclose(fp) != 0 || bad) ? STCSP_E_INVALID : STCSP_OK;
+    }
+    int read_binary(const char *path) {
+        FILE *fp = fopen(path, "rb");
+        if (!fp) return STCSP_E_INVALID;
+        bool ok = true;
+        auto get = [&](void *ptr, size_t bytes) { if (bytes && fread(ptr, 1, bytes, fp) != bytes) ok = false; };
+        char magic[8] = {0};
+        uint32_t h[6] = {0};
+        uint64_t table = 0, ns = 0, ne = 0;
+        get(magic, 8);
+        get(h, sizeof h);
+        get(&table, 8);
+        get(&ns, 8);
+        get(&ne, 8);
+        if (!ok || memcmp(magic, kMagic, 8) != 0 || h[0] != 1 || (h[5] != 1 && h[5] != 4) || h[1] > (1u << 20) || h[2] > (1u << 20) ||
+            ns > (1ull << 32) || ne > (1ull << 36)) {
+            fclose(fp);
+            return STCSP_E_INVALID;
+        }
+        n_vars = (int)h[1];
+        sig_len = (int)h[2];
+        n_sig_vars = (int)h[3];
+        n_until = (int)h[4];
+        names.clear();
+        var_lb.clear();
+        var_ub.clear();
+        is_sig.clear();
+        for (int i = 0; i < n_vars && ok; i++) {
+            int32_t b[2] = {0, 0};
+            uint8_t sg = 0;
+            uint16_t nl = 0;
+            get(b, 8);
+            get(&sg, 1);
+            get(&nl, 2);
+            std::string nm(nl, ' ');
+            get(&nm[0], nl);
+            var_lb.push_back(b[0]);
+            var_ub.push_back(b[1]);
+            is_sig.push_back(sg);
+            names.push_back(nm);
+        }
+        table_states = (int64_t)table;
+        n_states = (int64_t)std::max<uint64_t>(ns, 1);  // an EMPTY automaton keeps an invalid root
+        std::vector<uint32_t> ids(ns), outdeg(ns), dsts(ne);
+        cid.assign(n_states, 0);
+        final_.assign(n_states, 0);
+        sig.assign((size_t)n_states * sig_len, 0);
+        get(ids.data(), ns * 4);
+        get(cid.data(), ns * 4);
+        get(final_.data(), ns);
+        get(sig.data(), ns * sig_len * 4);
+        get(outdeg.data(), ns * 4);
+        get(dsts.data(), ne * 4);
+        eval.assign((size_t)ne * n_vars, 0);
+        if (h[5] == 1) {
+            std::vector<uint8_t> v8((size_t)ne * n_vars);
+            get(v8.data(), v8.size());
+            for (size_t k = 0; k < v8.size(); k++) eval[k] = var_lb[k % n_vars] + v8[k];
+        } else {
+            get(eval.data(), eval.size() * 4);
+        }
         fclose(fp);
+        uint64_t sum = 0;
+        for (uint32_t d : outdeg) sum += d;
+        for (uint32_t d : dsts) ok = ok && d < ns;
+        if (!ok || sum != ne) return STCSP_E_INVALID;
+        id.assign(n_states, 0);
+        for (uint64_t v = 0; v < ns; v++) id[v] = ids[v];
+        fail.assign(n_states, 0);
+        valid.assign(n_states, ns ? 1 : 0);
+        esrc.clear();
+        edst.assign(dsts.begin(), dsts.end());
+        for (uint64_t v = 0; v < ns; v++) esrc.insert(esrc.end(), outdeg[v], (int64_t)v);
+        ealive.assign(ne, 1);
+        build_csr();
         return STCSP_OK;
     }
 
     // SURVEY.md Appendix A.7 (normative script: tests/canon.py)
-    std::string canonical(int64_t *n_live_states, int64_t *n_live_edges) const {
-        std::string out = name_line() + "\n" + sig_name_line() + "\n";
+    std::string canonical(int64_t *n_live_states, int64_t *n_live_edges, bool want_text = true) const {
+        TextOut out(nullptr, want_text ? (1u << 22) : 4096);
+        out.str(name_line());
+        out.ch('\n');
+        out.str(sig_name_line());
+        out.ch('\n');
         int64_t ns = 0, ne = 0;
         if (!valid[0]) {
-            out += "EMPTY\n";
+            out.lit("EMPTY\n");
         } else {
             std::vector<int64_t> num(n_states, -1), order;
             std::map<int, int> cidmap;
-            auto sorted_out = [&](int64_t u) {
-                std::vector<int64_t> es;
+            std::vector<int64_t> sorted_edges, sorted_off{0};  // per state in `order`: live out-edges sorted by label
+            auto sort_out = [&](int64_t u) {
+                const size_t b = sorted_edges.size();
                 for (int64_t k = out_off[u]; k < out_off[u + 1]; k++)
-                    if (ealive[out_edge[k]]) es.push_back(out_edge[k]);
-                std::sort(es.begin(), es.end(), [&](int64_t a, int64_t b) {
-                    int c = 0;
-                    for (int i = 0; i < n_vars && c == 0; i++) {
-                        int x = eval[a * n_vars + i], y = eval[b * n_vars + i];
-                        c = (x < y) ? -1 : (x > y);
-                    }
-                    if (c) return c < 0;
-                    return a < b;
+                    if (ealive[out_edge[k]]) sorted_edges.push_back(out_edge[k]);
+                std::sort(sorted_edges.begin() + b, sorted_edges.end(), [&](int64_t a, int64_t b2) {
+                    const int32_t *x = &eval[a * n_vars], *y = &eval[b2 * n_vars];
+                    for (int i = 0; i < n_vars; i++)
+                        if (x[i] != y[i]) return x[i] < y[i];
+                    return a < b2;
                 });
-                return es;
+                sorted_off.push_back((int64_t)sorted_edges.size());
             };
             num[0] = 0;
             order.push_back(0);
             for (size_t q = 0; q < order.size(); q++) {
-                int64_t u = order[q];
-                for (int64_t e : sorted_out(u)) {
-                    int64_t v = edst[e];
+                sort_out(order[q]);
+                for (int64_t k = sorted_off[q]; k < sorted_off[q + 1]; k++) {
+                    int64_t v = edst[sorted_edges[k]];
                     if (num[v] < 0) {
                         num[v] = (int64_t)order.size();
                         order.push_back(v);
                     }
                 }
             }
-            for (int64_t u : order) {
-                if (!cidmap.count(cid[u])) {
-                    int k = (int)cidmap.size();
-                    cidmap[cid[u]] = k;
-                }
-                out += "S " + std::to_string(num[u]) + " " + std::to_string(cidmap[cid[u]]) + " " +
-                       std::to_string((int)final_[u]) + " " + sig_text(u, " ") + "\n";
-                for (int64_t e : sorted_out(u)) {
-                    out += "E " + std::to_string(num[u]) + " " + std::to_string(num[edst[e]]);
-                    for (int i = 0; i < n_vars; i++) out += " " + std::to_string(eval[e * n_vars + i]);
-                    out += "\n";
-                    ne++;
+            ns = (int64_t)order.size();
+            ne = (int64_t)sorted_edges.size();
+            if (want_text) {
+                LabelTable labels(*this, " ");
+                for (size_t q = 0; q < order.size(); q++) {
+                    const int64_t u = order[q];
+                    if (!cidmap.count(cid[u])) {
+                        int k = (int)cidmap.size();
+                        cidmap[cid[u]] = k;
+                    }
+                    out.lit("S ");
+                    out.num(num[u]);
+                    out.ch(' ');
+                    out.num(cidmap[cid[u]]);
+                    out.ch(' ');
+                    out.num((int)final_[u]);
+                    out.ch(' ');
+                    out.str(sig_text(u, " "));
+                    out.ch('\n');
+                    for (int64_t k = sorted_off[q]; k < sorted_off[q + 1]; k++) {
+                        const int64_t e = sorted_edges[k];
+                        out.lit("E ");
+                        out.num(num[u]);
+                        out.ch(' ');
+                        out.num(num[edst[e]]);
+                        out.ch(' ');
+                        labels.put(out, e);
+                        out.ch('\n');
+                    }
                 }
             }
-            ns = (int64_t)order.size();
         }
         if (n_live_states) *n_live_states = ns;
         if (n_live_edges) *n_live_edges = ne;
-        return out;
+        return out.take();
     }
 };
 
@@ -410,6 +749,19 @@ int stcsp_automaton_renumber(stcsp_automaton *a) {
     return STCSP_OK;
 }
 int stcsp_automaton_write_dot(const stcsp_automaton *a, const char *path) { return a ? a->a.write_dot(path) : STCSP_E_INVALID; }
+int stcsp_automaton_write_binary(const stcsp_automaton *a, const char *path) { return a && path ? a->a.write_binary(path) : STCSP_E_INVALID; }
+int stcsp_automaton_read_binary(const char *path, stcsp_automaton **out) {
+    if (!path || !out) return STCSP_E_INVALID;
+    stcsp_automaton *h = new stcsp_automaton();
+    h->root_final = 0;
+    int rc = h->a.read_binary(path);
+    if (rc != STCSP_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return STCSP_OK;
+}
 
 char *stcsp_automaton_canonical(const stcsp_automaton *a, size_t *len) {
     if (!a) return nullptr;
@@ -419,15 +771,15 @@ char *stcsp_automaton_canonical(const stcsp_automaton *a, size_t *len) {
     if (len) *len = s.size();
     return p;
 }
-int64_t stcsp_automaton_num_states(const stcsp_automaton *a) { return a->a.n_states; }
+int64_t stcsp_automaton_num_states(const stcsp_automaton *a) { return a->a.table_states >= 0 ? a->a.table_states : a->a.n_states; }
 int64_t stcsp_automaton_num_live_states(const stcsp_automaton *a) {
     int64_t ns = 0;
-    a->a.canonical(&ns, nullptr);
+    a->a.canonical(&ns, nullptr, false);
     return ns;
 }
 int64_t stcsp_automaton_num_live_edges(const stcsp_automaton *a) {
     int64_t ne = 0;
-    a->a.canonical(nullptr, &ne);
+    a->a.canonical(nullptr, &ne, false);
     return ne;
 }
 

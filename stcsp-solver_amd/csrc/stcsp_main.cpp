@@ -2,7 +2,10 @@
 // (src/stcsp.y:180-219 main, src/solver.cpp:195-359 solve): same flags, same stdout contract,
 // same solutions.dot. The search itself runs on the MI355X engine behind the C-ABI.
 //
-//   stcsp [-s] [-m<sec>] [-t] [-a] [-z] [-k<K>] [-l<level>] input.csp
+//   stcsp [-s] [-m<sec>] [-t] [-a] [-z] [-k<K>] [-l<level>] [--binary=<file>] input.csp
+//
+// --binary=<file> (not in the reference) additionally writes the printed automaton in the compact
+// binary form of include/stcsp_host.h.
 //
 // Options must be glued to their value (-k3, not -k 3): like the reference, the first argument
 // that does not start with '-' is the input file (stcsp.y:199-206).
@@ -28,6 +31,7 @@ struct Flags {
     bool print_solution = false, testing = false, adv1 = false, adv2 = false;
     int prefix_k = 2, time_limit = 0;
     const char *file = nullptr;
+    const char *binary = nullptr;
 };
 
 static int run_once(const Flags &f, bool print_line, double *total) {
@@ -83,6 +87,7 @@ static int run_once(const Flags &f, bool print_line, double *total) {
     stcsp_automaton_renumber(a);
     double proc_time = cpu_time() - t_proc;
     if (f.print_solution) stcsp_automaton_write_dot(a, "solutions.dot");
+    if (f.binary && stcsp_automaton_write_binary(a, f.binary) != STCSP_OK) fprintf(stderr, "cannot write %s\n", f.binary);
     if (print_line) {
         // init_time, var, con, dom, node, fail, solve_time, processTime (solveralgorithm.cpp:1001)
         printf("%.2f\t%d\t%d\t%d\t%d\t%d\t%.2f\t%.5f\n", init_time, p->n_vars, p->n_constraints, (int)res.counters.dominance,
@@ -102,6 +107,10 @@ int main(int argc, char **argv) {
         const char *a = argv[i];
         if (a[0] != '-') {
             if (!f.file) f.file = a;
+            continue;
+        }
+        if (strncmp(a, "--binary=", 9) == 0) {
+            f.binary = a + 9;
             continue;
         }
         switch (a[1]) {

@@ -1,0 +1,69 @@
+"""solutions.dot writer and the compact binary automaton format,
+on oracle results (CPU)."""
+import os
+
+import pytest
+
+from conftest import finish
+
+
+def dot_lines(a, path):
+    a.write_dot(str(path))
+    return path.read_text().splitlines()
+
+
+@pytest.mark.parametrize("name", ["juggling_b4_f5", "digitinvader3", "juggling_b4_f5_nosym", "partialorder_10"])
+def test_binary_roundtrip(stcsp, RefOracle, tmp_path, name):
+    m = stcsp.Model.from_name(name)
+    o = RefOracle(m)
+    a, _ = finish(o, o.solve())
+    p = tmp_path / "a.bin"
+    a.write_binary(str(p))
+    b = stcsp.Automaton.read_binary(str(p))
+    assert b.canonical() == a.canonical()
+    assert (b.n_states, b.n_live_states, b.n_live_edges) == (a.n_states, a.n_live_states, a.n_live_edges)
+    la, lb = dot_lines(a, tmp_path / "a.dot"), dot_lines(b, tmp_path / "b.dot")
+    assert la[:4] == lb[:4]                      # header comment lines + digraph opener
+    assert sorted(la) == sorted(lb)              # same vertex / edge lines, printed ids preserved
+    # the binary form is several times smaller than the text
+    assert os.path.getsize(p) * 2 < os.path.getsize(tmp_path / "a.dot")
+
+
+def test_binary_empty_and_corrupt(stcsp, RefOracle, tmp_path):
+    text = ("var d0:[0,0]; var d1:[0,0]; var d2:[0,0]; var d3:[0,0]; var d4:[0,0]; var e:[0,1]; var p:[0,1]; var s:[0,2]; "
+            "first s == 0; next s == if (e eq p) then 0 else 2; s <= 1;")
+    m = stcsp.Model(text=text)
+    o = RefOracle(m)
+    a, adv = finish(o, o.solve(), adversarial="z")
+    assert adv == 0 and a.canonical().endswith("EMPTY\n")
+    p = tmp_path / "e.bin"
+    a.write_binary(str(p))
+    b = stcsp.Automaton.read_binary(str(p))
+    assert b.canonical() == a.canonical()
+    raw = p.read_bytes()
+    (tmp_path / "bad1.bin").write_bytes(b"NOTMAGIC" + raw[8:])
+    (tmp_path / "bad2.bin").write_bytes(raw[: len(raw) // 2])
+    for bad in ("bad1.bin", "bad2.bin", "missing.bin"):
+        with pytest.raises(stcsp.StcspError):
+            stcsp.Automaton.read_binary(str(tmp_path / bad))
+
+
+def test_dot_format_lines(stcsp, RefOracle, tmp_path):
+    """Line formats of solverOut / vertexOut / edgeOut (src/solveralgorithm.cpp:709-730,
+    src/graph.cpp:41-101) incl. negative values (digitinvader domains start at -1)."""
+    m = stcsp.Model.from_name("digitinvader2")
+    o = RefOracle(m)
+    a, _ = finish(o, o.solve())
+    lines = dot_lines(a, tmp_path / "s.dot")
+    assert lines[0] == f"# Number of nodes = {a.n_states}"
+    assert lines[1].startswith("# ") and lines[2].startswith("# ") and lines[3] == 'digraph "StCSP" {' and lines[-1] == "}"
+    import re
+    vertex = re.compile(r'^\d+ \[shape=(double)?circle, label="(\d+: (-?\d+(, -?\d+)*)?|0: S)"\];$')
+    edge = re.compile(r'^\d+ -> \d+ \[label="-?\d+(, -?\d+)*"\];$')
+    body = lines[4:-1]
+    assert body and all(vertex.match(l) or edge.match(l) for l in body)
+    assert sum(1 for l in body if edge.match(l)) == a.n_live_edges
+    assert sum(1 for l in body if vertex.match(l)) == a.n_live_states
+    assert any("-1" in l for l in body)
+    n_vals = {len(l.split('"')[1].split(", ")) for l in body if edge.match(l)}
+    assert n_vals == {m.n_vars}
