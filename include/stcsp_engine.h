@@ -110,6 +110,9 @@ typedef struct stcsp_options {
 #define STCSP_F_NO_EXPORT 2      /* solve() leaves the automaton on the device; call
                                     stcsp_engine_export() to copy it out (bench: HBM-resident)     */
 #define STCSP_F_PROFILE 4        /* bracket every k_expand launch with HIP events (roofline)       */
+#define STCSP_F_STEPPED 8        /* run the sharded pipeline (leaves emit successor candidates, the
+                                    owner commits them: begin/expand_local/outbox/commit/finish) even
+                                    with world == 1 -- measures/tests that pipeline on a single GPU   */
 
 typedef struct stcsp_counters {
     int64_t search_nodes; /* node expansions = propagation-to-fixpoint + classification; the

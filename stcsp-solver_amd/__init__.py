@@ -85,6 +85,7 @@ class PostResult(C.Structure):
 F_KEEP_RAW_EDGES = 1
 F_NO_EXPORT = 2
 F_PROFILE = 4
+F_STEPPED = 8
 GID_SHIFT = 40
 
 ENGINE_SYMBOLS = [
@@ -445,6 +446,13 @@ class EngineBase:
         n = C.c_int64()
         self._check(self._f("sets_blob")(self._h, C.byref(p), C.byref(n)))
         return [p[i] for i in range(n.value)]
+
+    def sets_count(self) -> int:
+        """Number of constraint sets this shard knows (word 0 of the registry blob)."""
+        p = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        self._check(self._f("sets_blob")(self._h, C.byref(p), C.byref(n)))
+        return p[0] if n.value else 0
 
     def sets_import(self, words):
         arr = (C.c_int32 * len(words))(*words)

@@ -91,7 +91,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         return;
     }
     // leaf
-    if (c.world == 1) {
+    if (!c.sharded) {
         // unsharded: commit right here, the leaf's data never leaves the registers
         CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, gw);
         if (co.ok && co.is_new) emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk);
@@ -178,7 +178,7 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
     if (status == PS_RUN && (unsigned long long)max_edges + maxtake > p->edge_cap) status = PS_NEED_EDGES;
     if (status == PS_RUN && ns + taken > p->state_cap) status = PS_NEED_STATES;
     if (status == PS_RUN && (ns + taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
-    if (status == PS_RUN && c.world > 1) {
+    if (status == PS_RUN && c.sharded) {
         int mc = 0;
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
         mc = wave_max(mc);

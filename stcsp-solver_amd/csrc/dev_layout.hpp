@@ -63,6 +63,7 @@ struct ImgOff {
 
 struct Ctx {
     int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
+    int sharded;  // leaves emit successor candidates for their owner (world > 1, or STCSP_F_STEPPED) instead of committing in place
     // the compiled program: one contiguous image of 32-bit words (sections at the offsets in `o`),
     // staged into LDS by every workgroup of k_expand when it fits; the bytecode and the
     // user arrays (potentially large) stay in global memory

@@ -106,6 +106,7 @@ struct stcsp_engine {
     uint32_t cand_cap = 0;
     DevBuf<Plan> d_plan;
     DevBuf<uint32_t> d_pq, d_ring, d_seq, d_pstack, d_parked;  // persistent mode
+    bool sharded = false;    // candidate / commit pipeline (world > 1 or STCSP_F_STEPPED)
     bool persist = false;    // STCSP_PERSIST=1: unsharded solves without budgets use k_persist (experimental)
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
     Ctx *h_ctx = nullptr;    // pinned staging copy
@@ -264,7 +265,8 @@ struct stcsp_engine {
         if (o) opt = *o;
         if (opt.world <= 0) opt.world = 1;
         if (opt.rank < 0 || opt.rank >= opt.world) return fail(STCSP_E_INVALID, "rank %d outside world %d", opt.rank, opt.world);
-        int rc = mgr.init(p, opt.world > 1);
+        sharded = opt.world > 1 || (opt.flags & STCSP_F_STEPPED) != 0;
+        int rc = mgr.init(p, sharded);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
         const int N = mgr.N, K = mgr.K;
         for (int v = 0; v < N; v++) {
@@ -293,6 +295,7 @@ struct stcsp_engine {
         ctx.CS = cand_stride(N, K, ctx.sig_len);
         ctx.ES = edge_stride(N);
         ctx.world = opt.world;
+        ctx.sharded = sharded ? 1 : 0;
         ctx.rank = opt.rank;
         DR = (N * K + 63) / 64;
         if (DR == 3) DR = 4;
@@ -321,9 +324,9 @@ struct stcsp_engine {
         rc = alloc_edges(small_pools ? 8u : 1u << 15);
         if (rc != STCSP_OK) return rc;
         // outbox: [owner][region] x cand_cap records. Unsharded: emptied after every launch.
-        cand_cap = (uint32_t)(opt.world > 1 ? std::max(4 * chunk_r, 4096) : chunk_r);
+        cand_cap = (uint32_t)(sharded ? std::max(4 * chunk_r, 4096) : chunk_r);
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
-        if (opt.world > 1) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
+        if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
         HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : (size_t)8 * R * chunk_r * ctx.NS));
         HIPCHK(d_plan.alloc(1));
@@ -787,7 +790,12 @@ struct stcsp_engine {
         for (int r = 0; r < R; r++) total += h_ctl[L.cand0 + (peer * R + r) * CST];
         // pack this peer's regions; each peer gets its own slice of the pack buffer
         if (d_pack.n < (size_t)opt.world * R * cand_cap * ctx.CS) HIPCHK(d_pack.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
-        uint32_t *dst = d_pack.p + (size_t)peer * R * cand_cap * ctx.CS;
+        // peers are packed back to back (peer p starts where p-1 ended), so the driver can hand the
+        // whole buffer to one all-to-all-v without gathering the slices first
+        size_t before = 0;
+        for (int q = 0; q < peer; q++)
+            for (int r = 0; r < R; r++) before += h_ctl[L.cand0 + (q * R + r) * CST];
+        uint32_t *dst = d_pack.p + before * ctx.CS;
         if (total) {
             hipLaunchKernelGGL(k_pack, dim3(std::min<uint32_t>(1024, (total * ctx.CS + 255) / 256)), dim3(256), 0, stream,
                                d_cand.p + (size_t)peer * R * cand_cap * ctx.CS, cand_cap, ctx.CS, d_ctl.p, L.cand0 + peer * R * CST, dst);
@@ -846,7 +854,7 @@ struct stcsp_engine {
 
     // graphTraverse / adversarialTraverse / adversarialTraverse2 on the device (dev_postproc.hpp)
     int postprocess(const stcsp_post_options *po, stcsp_post_result *out) {
-        if (opt.world != 1) return fail(STCSP_E_STATE, "device post-processing is for unsharded engines (merge shards on the host)");
+        if (sharded) return fail(STCSP_E_STATE, "device post-processing is for unsharded engines (merge shards on the host)");
         if (!exp_on_device) return fail(STCSP_E_STATE, "postprocess needs the device export of a finished solve (export first)");
         const int N = ctx.N;
         const int a1 = po ? po->adversarial_var : -1, op = po ? po->adversarial2_op : -1, ava = po ? po->adversarial2_ava : -1;
@@ -1069,7 +1077,7 @@ struct stcsp_engine {
         auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipSetDevice(device));
         const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N, ES = ctx.ES;
-        if (opt.world == 1 && !(opt.flags & STCSP_F_KEEP_RAW_EDGES) && !getenv("STCSP_HOST_EXPORT")) {
+        if (!sharded && !(opt.flags & STCSP_F_KEEP_RAW_EDGES) && !getenv("STCSP_HOST_EXPORT")) {
             stcsp_counters ctr{};
             int rcc = read_counters(ctr);
             if (rcc != STCSP_OK) return rcc;
@@ -1132,7 +1140,7 @@ struct stcsp_engine {
             if (rcc != STCSP_OK) return rcc;
         }
         r_fail.assign(n_states, 0);
-        if (opt.world == 1) {
+        if (!sharded) {
             // ok-fixpoint over the raw leaf-edge log (okfix.hpp); sharded runs do it after the merge
             std::vector<uint8_t> alive;
             ok_fixpoint(n_states, r_esrc, r_edst, r_fail, alive);
@@ -1201,7 +1209,7 @@ int stcsp_engine_create(const stcsp_problem *problem, const stcsp_options *optio
 
 int stcsp_engine_solve(stcsp_engine *e, stcsp_result *result) {
     if (!e || !result) return STCSP_E_INVALID;
-    if (e->opt.world != 1) return e->fail(STCSP_E_STATE, "solve() is the unsharded entry point; use the stepping calls when world > 1");
+    if (e->sharded) return e->fail(STCSP_E_STATE, "solve() is the unsharded entry point; use the stepping calls when world > 1 or STCSP_F_STEPPED");
     int rc = e->solve_unsharded();
     if (rc != STCSP_OK) return rc;
     if (e->opt.flags & STCSP_F_NO_EXPORT) {

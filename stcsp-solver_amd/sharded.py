@@ -53,7 +53,9 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
     csw = engine.candidate_bytes() // 4
     engine.begin()
     comm_dev = torch.device("cpu") if (stage_through_host or device.type == "cpu") else device
-    last_sets = None
+    # every shard starts from the same registry (the model's own sets, plus whatever earlier solves
+    # on these engines exchanged), so the definitions only travel once somebody's count moves
+    last_sets = [engine.sets_count()] * world
     rounds = 0
     while True:
         rounds += 1
@@ -61,7 +63,7 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
             raise RuntimeError("sharded solve did not terminate")
         left = engine.expand_local()
         outs = [engine.outbox(p) for p in range(world)]  # (ptr, record count) per peer
-        n_sets = engine.sets_blob()[0]
+        n_sets = engine.sets_count()
         meta = torch.tensor([c for _, c in outs] + [left, n_sets], dtype=torch.int64, device=comm_dev)
         allmeta = [torch.empty_like(meta) for _ in range(world)]
         dist.all_gather(allmeta, meta)
@@ -76,8 +78,12 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
             last_sets = sets_now
         send_counts = [c for _, c in outs]
         recv_counts = [allmeta[p][rank] for p in range(world)]
-        send = torch.cat([_view(p, c * csw, device) for p, c in outs]) if sum(send_counts) else torch.empty(
-            0, dtype=torch.int32, device=device)
+        if sum(send_counts) == 0:
+            send = torch.empty(0, dtype=torch.int32, device=device)
+        elif all(outs[p + 1][0] == outs[p][0] + outs[p][1] * csw * 4 for p in range(world - 1)):
+            send = _view(outs[0][0], sum(send_counts) * csw, device)  # the engine packs peers back to back
+        else:
+            send = torch.cat([_view(p, c * csw, device) for p, c in outs])
         if comm_dev != device:
             send = send.to(comm_dev)
         recv = torch.empty(sum(recv_counts) * csw, dtype=torch.int32, device=comm_dev)

@@ -18,7 +18,11 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
     sh = importlib.import_module("stcsp-solver_amd.sharded")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend_kind == "hip-nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     m = st.Model.from_name(name, prefix_k=prefix_k)
     if backend_kind == "fmodel":
         # CPU stand-in for the HIP engine (tests only): oracle/frontier_model.cpp
@@ -34,6 +38,20 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         eng = FModel(m, rank=rank, world=world)
         device = torch.device("cpu")
         rounds = sh.solve_sharded(eng, rank, world, device)
+    elif backend_kind == "hip-nccl":
+        # the production N>1 code path on one GPU: RCCL process group of size 1, candidates stay in
+        # HBM (all_to_all_single on views of the engine's outbox), STCSP_F_STEPPED forces the
+        # candidate/commit pipeline although world == 1
+        import time
+        assert world == 1
+        eng = st.Engine(m, device=0, rank=0, world=1, flags=st.F_STEPPED)
+        device = torch.device("cuda:0")
+        rounds = sh.solve_sharded(eng, rank, world, device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rounds = sh.solve_sharded(eng, rank, world, device)
+        torch.cuda.synchronize()
+        stepped_ms = (time.perf_counter() - t0) * 1e3
     else:
         # the real HIP engine, every shard on GPU 0, all-to-all staged through host (gloo)
         eng = st.Engine(m, device=0, rank=rank, world=world)
@@ -46,6 +64,8 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         out = dict(states=a.n_live_states, edges=a.n_live_edges, sha=a.canonical_sha256(), rounds=rounds,
                    table=res.n_states, dom=res.counters.dominance, nodes=res.counters.search_nodes,
                    sets=res.n_constraint_sets)
+        if backend_kind == "hip-nccl":
+            out["stepped_ms"] = stepped_ms
         Path(out_path).write_text(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

@@ -57,3 +57,15 @@ def test_sharded_hip_engine_one_gpu(golden, tmp_path, world, name):
     g = golden[name]
     assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
     assert r["dom"] == g["dom"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["juggling_b4_f5", "digitinvader3", "partialorder_12"])
+def test_sharded_pipeline_rccl_world1(golden, tmp_path, name):
+    """The N>1 code path with the RCCL ("nccl") backend and device-resident candidate exchange,
+    as far as one GPU allows: process group of size 1, STCSP_F_STEPPED engine."""
+    r = launch(1, name, "hip-nccl", tmp_path)
+    g = golden[name]
+    assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+    assert r["dom"] == g["dom"]
+    print(f"{name}: sharded pipeline on one GPU: {r['rounds']} supersteps, {r['stepped_ms']:.2f} ms")
