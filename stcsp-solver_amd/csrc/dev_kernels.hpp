@@ -39,85 +39,129 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     hd.set = (int)(w2 & 0xffffu);
     hd.seed = w2 >> 16;
     hd.expire = rflu(node[3]);
-    BranchOut bo;
-    LeafOut<DR> lo;
-    const unsigned long long t_b = PHASE_NOW();
-    const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
-    const unsigned long long t_c = PHASE_NOW();
-    (void)t_b;
-    (void)t_c;
-#ifdef STCSP_PHASES
-    // everything after process_node (child stores / commit / candidate) is charged to "commit"
-    struct PhaseEnd {
-        const Ctx &c; int gw, lane; unsigned long long ta, tb, tc;
-        __device__ ~PhaseEnd() {
-            if (lane == 0) {
-                const unsigned long long td = PHASE_NOW();
-                add_stats(c, gw, ST_CYC_LOAD, tb - ta);
-                add_stats(c, gw, ST_CYC_CLASSIFY, tc - tb);  // whole process_node (incl. sweeps + wavefront revisions)
-                add_stats(c, gw, ST_CYC_COMMIT, td - tc);
-                add_stats(c, gw, ST_CYC_TOTAL, td - ta);
-            }
-        }
-    } phase_end{c, gw, lane, t_a, t_b, t_c};
-#endif
-    if (oc == OC_FAIL) return;
+    // A wavefront does not stop after one expansion: it keeps the lower child of a bisection (or the
+    // first node of a state its leaf just opened) in registers and expands it too, up to `chain`
+    // expansions per slot -- depth-first inside the slot, breadth-first across slots. The planner
+    // picks `chain` per round: long chains while the frontier is smaller than the machine (each
+    // round costs ~20 us whatever its size), short ones when there are more slots than wavefronts.
+    // Chains pay off while the fixed cost of a round (launch gap, image staging, bookkeeping: ~15 us)
+    // is comparable to an expansion; after an expensive expansion (digitinvader / juggling revisions
+    // run for 100+ us) continuing would only serialise work other wavefronts could take next round,
+    // so a slot also stops chaining once it has used `chain_cycles` of this launch.
+    const int chain = kload(c.plan, (int)(offsetof(Plan, chain) / 4));
+    const unsigned long long chain_cycles = (unsigned long long)(unsigned)kload(c.plan, (int)(offsetof(Plan, chain_heavy) / 4));
+    const unsigned long long t_slot = __builtin_amdgcn_s_memtime();
     uint32_t *out_region = a.out_base + (size_t)ro * a.out_cap * c.NS;
-    if (oc == OC_BRANCH) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 2u);
-        pos = rflu(pos);
-        if (pos + 2 > a.out_cap) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+    const unsigned long long t_b = PHASE_NOW();
+    (void)t_b;
+#ifdef STCSP_PHASES
+    if (lane == 0) add_stats(c, gw, ST_CYC_LOAD, t_b - t_a);
+#endif
+    for (int step = 1;; step++) {
+        BranchOut bo;     // outputs of this expansion only (nothing of them is carried round the loop)
+        LeafOut<DR> lo;
+        // The header is wave-uniform, but values carried round a loop whose exits the compiler cannot
+        // prove uniform are treated as divergent (VGPRs, vector instead of scalar descriptor loads:
+        // +30..60 VGPRs and a wavefront of occupancy per SIMD). Pin them to SGPRs every iteration.
+        hd.h0 = rflu(hd.h0);
+        hd.h1 = rflu(hd.h1);
+        hd.set = rfl(hd.set);
+        hd.seed = rflu(hd.seed);
+        hd.expire = rflu(hd.expire);
+        const unsigned long long t_p = PHASE_NOW();
+        const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+        const bool last = step >= chain || __builtin_amdgcn_s_memtime() - t_slot > chain_cycles;
+        const unsigned long long t_c = PHASE_NOW();
+        (void)t_p;
+        (void)t_c;
+#ifdef STCSP_PHASES
+        // everything after process_node (child stores / commit / candidate) is charged to "commit"
+        struct PhaseEnd {
+            const Ctx &c; int gw, lane; unsigned long long tp, tc;
+            __device__ ~PhaseEnd() {
+                if (lane == 0) {
+                    const unsigned long long td = PHASE_NOW();
+                    add_stats(c, gw, ST_CYC_CLASSIFY, tc - tp);  // whole process_node (incl. sweeps + wavefront revisions)
+                    add_stats(c, gw, ST_CYC_COMMIT, td - tc);
+                    add_stats(c, gw, ST_CYC_TOTAL, td - tp);
+                }
+            }
+        } phase_end{c, gw, lane, t_p, t_c};
+#endif
+        if (oc == OC_FAIL) return;
+        if (oc == OC_BRANCH) {
+            const uint32_t n_out = last ? 2u : 1u;
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], n_out);
+            pos = rflu(pos);
+            if (pos + n_out > a.out_cap) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+                return;
+            }
+            const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
+            Dom<DR> child = dom;
+            child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: always to the frontier
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
+            dom.set(bo.bvar, bo.D & bo.lowmask, lane);     // lower half: next in the chain, or stored too
+            if (last) {
+                store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, dom, lane);
+                return;
+            }
+            hd.seed = (uint32_t)(bo.bvar + 1);
+            continue;
+        }
+        if (oc == OC_MISS) {  // park the (propagated) node again until the host has translated the set
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
+            pos = rflu(pos);
+            if (pos + 1 > a.out_cap) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+                return;
+            }
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
             return;
         }
-        Dom<DR> child = dom;
-        child.set(bo.bvar, bo.D & bo.lowmask, lane);
-        const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
-        store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
-        child.set(bo.bvar, bo.D & ~bo.lowmask, lane);
-        store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
-        return;
-    }
-    if (oc == OC_MISS) {  // park the (propagated) node again until the host has translated the set
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
-        pos = rflu(pos);
-        if (pos + 1 > a.out_cap) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+        // leaf
+        if (c.sharded) {  // candidate record for the owner: header, signature, edge label, block
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
+            pos = rflu(pos);
+            if (pos + 1 > a.cand_cap) {
+                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
+                return;
+            }
+            uint32_t *rec = a.cand_base + ((size_t)(lo.owner * R + ro) * a.cand_cap + pos) * c.CS;
+            if (lane < 6)
+                rec[lane] = lane == 0 ? hd.h0
+                          : (lane == 1 ? hd.h1
+                          : (lane == 2 ? lo.next_tag : (lane == 3 ? lo.new_expire : (lane == 4 ? (uint32_t)lo.h : (uint32_t)(lo.h >> 32)))));
+            if (lane >= 1 && lane <= c.sig_len) rec[kCandHdr + lane - 1] = lo.kw;
+            uint32_t *vals = rec + kCandHdr + c.sig_len;
+            uint32_t *blk = vals + c.N;
+#pragma unroll
+            for (int q = 0; q < DR; q++) {
+                int idx = q * 64 + lane;
+                if (idx < c.N) vals[idx] = lo.evals[q];
+                if (idx < c.NK) blk[idx] = lo.nblk[q];
+            }
             return;
         }
-        store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
-        return;
-    }
-    // leaf
-    if (!c.sharded) {
         // unsharded: commit right here, the leaf's data never leaves the registers
         CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, gw);
-        if (co.ok && co.is_new) emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk);
-        return;
-    }
-    // sharded: candidate record for the owner: header, signature, edge label, block
-    uint32_t pos = 0;
-    if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
-    pos = rflu(pos);
-    if (pos + 1 > a.cand_cap) {
-        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
-        return;
-    }
-    uint32_t *rec = a.cand_base + ((size_t)(lo.owner * R + ro) * a.cand_cap + pos) * c.CS;
-    if (lane < 6)
-        rec[lane] = lane == 0 ? hd.h0
-                  : (lane == 1 ? hd.h1
-                  : (lane == 2 ? lo.next_tag : (lane == 3 ? lo.new_expire : (lane == 4 ? (uint32_t)lo.h : (uint32_t)(lo.h >> 32)))));
-    if (lane >= 1 && lane <= c.sig_len) rec[kCandHdr + lane - 1] = lo.kw;
-    uint32_t *vals = rec + kCandHdr + c.sig_len;
-    uint32_t *blk = vals + c.N;
+        if (!(co.ok && co.is_new)) return;
+        if (last) {
+            emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk);
+            return;
+        }
+        // the leaf opened a new state: its first node is next in the chain
+        const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
+        hd.h0 = (uint32_t)gid;
+        hd.h1 = (uint32_t)(gid >> 32);
+        hd.set = co.set;
+        hd.seed = 0;
+        hd.expire = lo.new_expire;
 #pragma unroll
-    for (int q = 0; q < DR; q++) {
-        int idx = q * 64 + lane;
-        if (idx < c.N) vals[idx] = lo.evals[q];
-        if (idx < c.NK) blk[idx] = lo.nblk[q];
+        for (int q = 0; q < DR; q++) dom.r[q] = lo.nblk[q];
     }
 }
 
@@ -170,19 +214,22 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
     const int take = cnt < chunk ? cnt : chunk;
     const int maxtake = wave_max(take);
     const long long taken = wave_sum64(take);
-    const unsigned out_cap = 3u * (unsigned)maxtake;
+    // expansions per slot this round (see expand_node): a slot emits at most chain + 1 nodes and
+    // chain leaves, all into one cursor region that receives from at most maxtake slots
+    const int chain = taken <= (long long)p->chain_thresh ? p->chain_small : p->chain_big;
+    const unsigned out_cap = (unsigned)(chain + 2) * (unsigned)maxtake;
     int status = PS_RUN;
     if (arena_top + (unsigned long long)R * out_cap * c.NS > p->arena_words) status = PS_NEED_ARENA;
     const unsigned max_edges = (unsigned)wave_max(rl ? (int)ald(&c.ctl[L.edge0 + lane * CST]) : 0);
     const unsigned long long ns = rflu(lane == 0 ? ald(&c.ctl[L.misc0 + MISC_NSTATES * CST]) : 0u);
-    if (status == PS_RUN && (unsigned long long)max_edges + maxtake > p->edge_cap) status = PS_NEED_EDGES;
-    if (status == PS_RUN && ns + taken > p->state_cap) status = PS_NEED_STATES;
-    if (status == PS_RUN && (ns + taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
+    if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)chain * maxtake > p->edge_cap) status = PS_NEED_EDGES;
+    if (status == PS_RUN && ns + chain * taken > p->state_cap) status = PS_NEED_STATES;
+    if (status == PS_RUN && (ns + chain * taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
     if (status == PS_RUN && c.sharded) {
         int mc = 0;
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
         mc = wave_max(mc);
-        if ((unsigned long long)mc + chunk > p->cand_cap) status = PS_OUTBOX_FULL;
+        if ((unsigned long long)mc + maxtake > p->cand_cap) status = PS_OUTBOX_FULL;  // a slot ends at its first leaf
     }
     if (status != PS_RUN) {
         if (lane == 0) p->status = status;
@@ -201,6 +248,7 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
         p->out_cap = out_cap;
         p->nslots = R * maxtake;
         p->parity = parity;
+        p->chain = chain;
         p->status = PS_RUN;
     }
 }
@@ -282,6 +330,8 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
     if ((int)blockIdx.x * 4 >= n_slots) return;
     const unsigned n_working = (unsigned)min((n_slots + 3) / 4, (int)gridDim.x);
     const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    const unsigned long long t_k0 = PHASE_NOW();
+    (void)t_k0;
     if (L) {
         const uint4 *src = (const uint4 *)c.img;
         uint4 *dst = (uint4 *)smem;
@@ -304,8 +354,17 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
         a.parity = p->parity;
     }
     const int total_waves = gridDim.x * 4;
+    const unsigned long long t_k1 = PHASE_NOW();
+    (void)t_k1;
     for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L>(c, a, P, gw, lane, lds_vals, lds_stk);
     __syncthreads();
+#ifdef STCSP_PHASES
+    if (threadIdx.x == 0) {
+        add_stats(c, blockIdx.x, ST_CYC_STAGE, t_k1 - t_k0);
+        add_stats(c, blockIdx.x, ST_BLOCKS, 1);
+        add_stats(c, blockIdx.x, ST_CYC_BLOCK, PHASE_NOW() - t_k0);
+    }
+#endif
     if (wib == 0) {
         unsigned t = 0;
         if (lane == 0) {
@@ -315,7 +374,15 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
         if (rflu(t) == n_working - 1) {  // last working workgroup: every cursor of this round is final
             if (lane == 0) c.plan->done_blocks = 0;
             __threadfence();
+            const unsigned long long t_k2 = PHASE_NOW();
+            (void)t_k2;
             finalize_round(c, c.plan, lane);
+#ifdef STCSP_PHASES
+            if (lane == 0) {
+                add_stats(c, 0, ST_CYC_FINAL, PHASE_NOW() - t_k2);
+                add_stats(c, 0, ST_ROUNDS_FINAL, 1);
+            }
+#endif
         }
     }
 }
@@ -423,6 +490,8 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    const unsigned long long t_k0 = PHASE_NOW();
+    (void)t_k0;
     if (L) {
         const uint4 *src = (const uint4 *)c.img;
         uint4 *dst = (uint4 *)smem;

@@ -12,10 +12,11 @@ namespace dev {
 constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
-constexpr int kStatWords = 24;
+constexpr int kStatWords = 28;
 enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
        ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
-       ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED };
+       ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED,
+       ST_CYC_STAGE, ST_BLOCKS, ST_CYC_FINAL, ST_ROUNDS_FINAL, ST_CYC_BLOCK };
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
@@ -49,6 +50,9 @@ struct Plan {
     unsigned long long in_base, out_base, arena_top, arena_words, slot_cap;
     unsigned in_cap, out_cap, edge_cap, state_cap, cand_cap, done_blocks;
     int chunk_r, world;
+    int chain;                                 // expansions per slot in the planned round
+    int chain_small, chain_big, chain_thresh;  // policy: chain_small while a round has <= chain_thresh nodes
+    int chain_heavy;                           // a slot stops chaining after this many cycles in one launch
     long long rounds, open_total;
     DevSegment stack[kMaxSegments];
 };

@@ -94,6 +94,11 @@ struct stcsp_engine {
     CtlLayout L{1};
     size_t lds_bytes = 0;
     int chunk_r = 0;  // max nodes taken per region per launch
+    // expansions per slot and launch (expand_node): chain_small while a round has <= chain_thresh
+    // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
+    // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). STCSP_CHAIN_SMALL / _BIG /
+    // _THRESH / _HEAVY override.
+    int chain_small = 4, chain_big = 2, chain_thresh = 4096, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
     int persist_blocks = 256 * 4;  // k_persist grid: must all be resident
 
@@ -106,6 +111,9 @@ struct stcsp_engine {
     uint32_t cand_cap = 0;
     DevBuf<Plan> d_plan;
     DevBuf<uint32_t> d_pq, d_ring, d_seq, d_pstack, d_parked;  // persistent mode
+    bool dbg_rounds = false;  // STCSP_DEBUG=2: per-launch log (with STCSP_BURST=1 and STCSP_F_PROFILE)
+    std::vector<unsigned long long> dbg_nodes;
+    std::vector<long long> dbg_open;
     bool sharded = false;    // candidate / commit pipeline (world > 1 or STCSP_F_STEPPED)
     bool persist = false;    // STCSP_PERSIST=1: unsharded solves without budgets use k_persist (experimental)
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
@@ -334,7 +342,12 @@ struct stcsp_engine {
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_CHAIN_SMALL")) chain_small = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_CHAIN_BIG")) chain_big = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_CHAIN_THRESH")) chain_thresh = std::max(0, atoi(ev));
+        if (const char *ev = getenv("STCSP_CHAIN_HEAVY")) chain_heavy = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_PERSIST")) persist = atoi(ev) != 0;
+        if (const char *ev = getenv("STCSP_DEBUG")) dbg_rounds = atoi(ev) >= 2;
         sync_ctx();
         return STCSP_OK;
     }
@@ -469,6 +482,10 @@ struct stcsp_engine {
         HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
         memset(h_plan, 0, sizeof(Plan));
         h_plan->chunk_r = chunk_r;
+        h_plan->chain_small = chain_small;
+        h_plan->chain_big = chain_big;
+        h_plan->chain_thresh = chain_thresh;
+        h_plan->chain_heavy = chain_heavy;
         h_plan->world = opt.world;
         if (opt.rank == 0) {
             // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
@@ -581,12 +598,20 @@ struct stcsp_engine {
             }
             rc = read_plan();
             if (rc != STCSP_OK) return rc;
+            if (dbg_rounds && burst == 1) {
+                std::vector<unsigned long long> st(kStatSlots * kStatWords);
+                HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                unsigned long long nodes = 0;
+                for (int sl = 0; sl < kStatSlots; sl++) nodes += st[sl * kStatWords + ST_NODES];
+                dbg_nodes.push_back(nodes);
+                dbg_open.push_back((long long)h_plan->open_total);
+            }
             switch (h_plan->status) {
                 case PS_RUN: break;
                 case PS_DONE:
                 case PS_OUTBOX_FULL: return STCSP_OK;
                 case PS_NEED_ARENA: {
-                    size_t need = (size_t)h_plan->arena_top + (size_t)R * 3 * chunk_r * ctx.NS;
+                    size_t need = (size_t)h_plan->arena_top + (size_t)R * (std::max(chain_small, chain_big) + 2) * chunk_r * ctx.NS;
                     if ((rc = grow_arena(need)) || (rc = push_caps()) || (rc = replan())) return rc;
                     break;
                 }
@@ -618,8 +643,8 @@ struct stcsp_engine {
     bool over_budget() {
         if (opt.time_limit_s > 0 && elapsed() > opt.time_limit_s) return true;
         if (opt.max_search_nodes > 0) {
-            // cheap upper bound without a device read: every launch expands at most R*chunk_r nodes
-            if (levels * (long long)R * chunk_r >= opt.max_search_nodes) {
+            // cheap upper bound without a device read: every launch expands at most chain*R*chunk_r nodes
+            if (levels * (long long)R * chunk_r * std::max(chain_small, chain_big) >= opt.max_search_nodes) {
                 std::vector<unsigned long long> st(kStatSlots * kStatWords);
                 if (hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                     long long nodes = 0;
@@ -750,6 +775,10 @@ struct stcsp_engine {
                     (double)tot[ST_CYC_LOAD] / tot[ST_NODES], (double)tot[ST_CYC_CLASSIFY] / tot[ST_NODES], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES],
                     (double)tot[ST_CYC_WAVE] / tot[ST_NODES], (double)tot[ST_CYC_COMMIT] / tot[ST_NODES],
                     (double)tot[ST_CYC_TOTAL] / tot[ST_NODES], (unsigned long long)tot[ST_NODES]);
+        if (tot[ST_BLOCKS] && tot[ST_ROUNDS_FINAL])
+            fprintf(stderr, "[phases] per working workgroup: image staging %.0f cycles, whole %.0f cycles (%llu workgroup runs); finalize_round %.0f cycles x %llu rounds\n",
+                    (double)tot[ST_CYC_STAGE] / tot[ST_BLOCKS], (double)tot[ST_CYC_BLOCK] / tot[ST_BLOCKS], (unsigned long long)tot[ST_BLOCKS],
+                    (double)tot[ST_CYC_FINAL] / tot[ST_ROUNDS_FINAL], (unsigned long long)tot[ST_ROUNDS_FINAL]);
 #endif
         ctr.levels = levels;
         ctr.seconds_search = finished ? seconds_search : elapsed();
@@ -767,7 +796,13 @@ struct stcsp_engine {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
             seconds_expand_kernel += ms * 1e-3;
+            if (dbg_rounds) {  // STCSP_DEBUG=2 with STCSP_BURST=1: one line per launch
+                const unsigned long long n1 = i < dbg_nodes.size() ? dbg_nodes[i] : 0, n0 = i ? dbg_nodes[i - 1] : 0;
+                fprintf(stderr, "[round] %3zu  %8.1f us  %8llu nodes  open after %lld\n", i, ms * 1e3, n1 - n0, i < dbg_open.size() ? dbg_open[i] : -1);
+            }
         }
+        dbg_nodes.clear();
+        dbg_open.clear();
         ev_used = 0;
         int rc = read_ctl();
         if (rc != STCSP_OK) return rc;
