@@ -159,11 +159,12 @@ def main():
         avg_launch_s = k_time / max(k_launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # HBM traffic of the same kernel from the committed PMC passes (bench.py cannot collect
-        # counters itself): profiles/r01_p14_traffic.json, per launch, gfx950-corrected
+        # counters itself): profiles/r01_chain_p14_traffic.json holds FETCH_SIZE + WRITE_SIZE summed
+        # over every k_expand dispatch of one solve (gfx950-corrected); per launch = / launches per solve
         traffic = None
-        tf = REPO / "profiles" / "r01_p14_traffic.json"
-        if args.workload == WORKLOAD and world == 1 and tf.exists():
-            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch_corrected"]
+        tf = REPO / "profiles" / "r01_chain_p14_traffic.json"
+        if args.workload == WORKLOAD and world == 1 and tf.exists() and k_launches:
+            traffic = json.loads(tf.read_text())["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
         out = {
             "metric": "search-tree nodes/sec on partialorder_14.csp",
             "value": nodes / elapsed,
