@@ -12,6 +12,7 @@ template <bool L>
 struct Img {
     const uint32_t *p;
     __device__ __forceinline__ int v(int off) const { return (int)p[off]; }
+    __device__ __forceinline__ uint4 v4(int off) const { return *(const uint4 *)(p + off); }  // off % 4 == 0
     __device__ __forceinline__ int u(int off) const;
 };
 // The compiled program (bytecode, descriptors, tables) is read-only for the lifetime of a launch
@@ -513,13 +514,21 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 unsigned long long dmask = __ballot(isd);
                 if (!dmask) continue;
                 ws.revs += (unsigned)__popcll(dmask);
-                ItemDesc it;
-                {
-                    const int ioff = c.o.items + (S.item_begin + (isd ? item : 0)) * (int)(sizeof(ItemDesc) / 4);
-                    int *dst = (int *)&it;
-#pragma unroll
-                    for (int k = 0; k < (int)(sizeof(ItemDesc) / 4); k++) dst[k] = P.v(ioff + k);
-                }
+                // the lane's item, unpacked from its 16-byte sweep record (device_types.hpp)
+                const uint4 sw = P.v4(c.o.sweep + (S.item_begin + (isd ? item : 0)) * 4);
+                struct {
+                    int idx[4], type, arity, r1, r2, aux, toff;
+                } it;
+                it.idx[0] = (int)(sw.x & 255u);
+                it.idx[1] = (int)((sw.x >> 8) & 255u);
+                it.idx[2] = (int)((sw.x >> 16) & 255u);
+                it.idx[3] = (int)(sw.x >> 24);
+                it.type = (int)(sw.y & 3u);
+                it.arity = (int)((sw.y >> 2) & 7u);
+                it.r1 = (int)((sw.y >> 5) & 63u);
+                it.r2 = (int)((sw.y >> 11) & 63u);
+                it.aux = (int)sw.y >> 17;
+                it.toff = (int)sw.z;
                 // gathers are executed by every lane (cross-lane reads need the source lanes active)
                 uint32_t D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
                 uint32_t D2 = dom.gather(it.idx[2]), D3 = dom.gather(it.idx[3]);

@@ -86,6 +86,23 @@ struct ItemDesc {
     int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal ; SMALL: number of table rows
 };
 
+// What the lane-per-item sweep needs of an ItemDesc, packed into one 16-byte record so that a
+// lane fetches its item with a single 128-bit LDS read:
+//   x = idx[0] | idx[1] << 8 | idx[2] << 16 | idx[3] << 24      (block word indices, N*K <= 256)
+//   y = type | arity << 2 | r1 << 5 | r2 << 11 | aux << 17       (aux signed: NEXT shift clamped to
+//                                                                  [-32, 32], UNTIL ordinal)
+//   z = toff
+inline void pack_sweep_item(const ItemDesc &it, uint32_t out[4]) {
+    auto byte = [](int32_t v) { return (uint32_t)(v < 0 ? 0 : v) & 0xffu; };
+    out[0] = byte(it.idx[0]) | byte(it.idx[1]) << 8 | byte(it.idx[2]) << 16 | byte(it.idx[3]) << 24;
+    int32_t aux = it.type == IT_SMALL ? 0 : it.aux;
+    if (it.type == IT_NEXT) aux = aux > 32 ? 32 : (aux < -32 ? -32 : aux);
+    out[1] = ((uint32_t)it.type & 3u) | ((uint32_t)it.arity & 7u) << 2 | ((uint32_t)it.r1 & 63u) << 5 | ((uint32_t)it.r2 & 63u) << 11 |
+             (uint32_t)aux << 17;
+    out[2] = (uint32_t)it.toff;
+    out[3] = 0u;
+}
+
 struct SetDesc {          // one constraint set (entry of Solver::seenConstraints)
     int32_t con_begin;    // into cons[]
     int32_t ncons;

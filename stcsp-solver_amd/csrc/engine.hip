@@ -212,6 +212,11 @@ struct stcsp_engine {
         o.scope = put(prog.scope.data(), prog.scope.size() * 4);
         o.strides = put(prog.strides.data(), prog.strides.size() * 4);
         o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
+        {
+            std::vector<uint32_t> sweep(prog.items.size() * 4);
+            for (size_t i = 0; i < prog.items.size(); i++) pack_sweep_item(prog.items[i], &sweep[i * 4]);
+            o.sweep = put(sweep.data(), sweep.size() * 4);
+        }
         o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
         o.var_lb = put(mgr.lb.data(), mgr.lb.size() * 4);
         o.var_init = put(init.data(), init.size() * 4);
@@ -254,6 +259,9 @@ struct stcsp_engine {
             if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
                 max_blocks = per_cu * prop.multiProcessorCount;
             if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
+            if (getenv("STCSP_DEBUG"))
+                fprintf(stderr, "[engine] image %d words (%s), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
+                        o.words, img_in_lds ? "in LDS" : "global", scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
             // the persistent kernel has its own register footprint
             switch (DR) {
                 case 1: fn = img_in_lds ? (const void *)k_persist<1, true> : (const void *)k_persist<1, false>; break;
