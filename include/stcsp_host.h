@@ -61,6 +61,10 @@ int stcsp_automaton_import_flags(stcsp_automaton *a, const uint8_t *state_valid,
                                  const uint8_t *edge_alive);
 /* Read the current flags back (any pointer may be NULL): [n_states], [n_states], [n_edges]. */
 int stcsp_automaton_flags(const stcsp_automaton *a, uint8_t *state_valid, uint8_t *state_final, uint8_t *edge_alive);
+/* Make the output order independent of the search's scheduling: out-edges of every state ordered by
+ * content (destination buckets by smallest label, edges by label). Call before renumber / write_dot /
+ * write_binary when the files must be reproducible byte for byte; O(E log E) label comparisons. */
+int stcsp_automaton_order_by_label(stcsp_automaton *a);
 /* renumberVertex (src/graph.cpp:420-442). */
 int stcsp_automaton_renumber(stcsp_automaton *a);
 

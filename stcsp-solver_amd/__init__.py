@@ -99,7 +99,7 @@ HOST_SYMBOLS = [
     "stcsp_host_last_error", "stcsp_model_constraint_string",
     "stcsp_automaton_build", "stcsp_automaton_free", "stcsp_automaton_traverse",
     "stcsp_automaton_adversarial", "stcsp_automaton_adversarial2", "stcsp_automaton_renumber",
-    "stcsp_automaton_import_flags", "stcsp_automaton_flags", "stcsp_automaton_write_binary", "stcsp_automaton_read_binary",
+    "stcsp_automaton_import_flags", "stcsp_automaton_flags", "stcsp_automaton_order_by_label", "stcsp_automaton_write_binary", "stcsp_automaton_read_binary",
     "stcsp_automaton_write_dot", "stcsp_automaton_canonical", "stcsp_automaton_num_states",
     "stcsp_automaton_num_live_states", "stcsp_automaton_num_live_edges",
     "stcsp_merge_shards", "stcsp_merged_result", "stcsp_merged_free", "stcsp_host_free",
@@ -150,6 +150,7 @@ def host_lib() -> C.CDLL:
         lib.stcsp_automaton_adversarial.argtypes = [C.c_void_p, C.c_int]
         lib.stcsp_automaton_adversarial2.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.stcsp_automaton_renumber.argtypes = [C.c_void_p]
+        lib.stcsp_automaton_order_by_label.argtypes = [C.c_void_p]
         lib.stcsp_automaton_import_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.stcsp_automaton_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.stcsp_automaton_write_dot.argtypes = [C.c_void_p, C.c_char_p]
@@ -292,6 +293,11 @@ class Automaton:
 
     def renumber(self):
         host_lib().stcsp_automaton_renumber(self._h)
+        return self
+
+    def order_by_label(self):
+        """Scheduling-independent output order (reproducible solutions.dot / binary files)."""
+        host_lib().stcsp_automaton_order_by_label(self._h)
         return self
 
     def import_flags(self, post: "PostResult"):

@@ -85,6 +85,7 @@ struct Automaton {
     std::vector<int32_t> cid, sig;
     std::vector<uint8_t> fail, valid, final_;
     std::vector<int64_t> id;  // printed vertex id (renumberVertex)
+    std::vector<int32_t> cid_print;  // order_by_label(): constraint-set ids renumbered by first visit of renumber()
     std::vector<int64_t> esrc, edst;
     std::vector<int32_t> eval;
     std::vector<uint8_t> ealive;
@@ -113,6 +114,40 @@ struct Automaton {
         for (int64_t v = 0; v < n_states; v++)
             std::stable_sort(out_edge.begin() + out_off[v], out_edge.begin() + out_off[v + 1],
                              [&](int64_t a, int64_t b) { return edst[a] < edst[b]; });
+    }
+
+    // State indices and the order of the edge arrays depend on the scheduling of the search, so the
+    // (dst, insertion) order above differs from run to run. For output files the out-edges of every
+    // state are re-ordered by content instead: destination buckets by their smallest label, edges
+    // inside a bucket by label (a label determines its destination, so this is a total order) --
+    // the same input then always gives the same solutions.dot / binary file.
+    void order_by_label() {
+        auto less = [&](int64_t a, int64_t b) {
+            const int32_t *x = &eval[a * n_vars], *y = &eval[b * n_vars];
+            for (int i = 0; i < n_vars; i++)
+                if (x[i] != y[i]) return x[i] < y[i];
+            return a < b;
+        };
+        std::vector<int64_t> rank(n_states, -1), touched;
+        for (int64_t v = 0; v < n_states; v++) {
+            auto b = out_edge.begin() + out_off[v], e = out_edge.begin() + out_off[v + 1];
+            if (e - b < 2) continue;
+            std::sort(b, e, less);
+            int64_t next = 0;
+            touched.clear();
+            for (auto it = b; it != e; ++it)
+                if (rank[edst[*it]] < 0) {
+                    rank[edst[*it]] = next++;
+                    touched.push_back(edst[*it]);
+                }
+            std::stable_sort(b, e, [&](int64_t x, int64_t y) { return rank[edst[x]] < rank[edst[y]]; });
+            for (int64_t d : touched) rank[d] = -1;
+        }
+        label_ordered = true;
+    }
+    bool label_ordered = false;
+    int32_t printed_cid(int64_t v) const {
+        return (label_ordered && cid[v] >= 0 && (size_t)cid[v] < cid_print.size() && cid_print[cid[v]] >= 0) ? cid_print[cid[v]] : cid[v];
     }
 
     // graphTraverse (graph.cpp:357-418)
@@ -230,12 +265,18 @@ struct Automaton {
         std::vector<uint8_t> seen(n_states, 0);
         std::vector<int64_t> stack{0};
         int64_t next = 0;
+        int32_t next_cid = 0;
+        cid_print.clear();
         while (!stack.empty()) {
             int64_t v = stack.back();
             stack.pop_back();
             if (seen[v]) continue;
             seen[v] = 1;
             id[v] = next++;
+            if (label_ordered && cid[v] >= 0) {  // set ids in the order this walk meets them (the search's
+                if ((size_t)cid[v] >= cid_print.size()) cid_print.resize(cid[v] + 1, -1);  // discovery order is scheduling-dependent)
+                if (cid_print[cid[v]] < 0) cid_print[cid[v]] = next_cid++;
+            }
             int64_t last = -1;
             for (int64_t k = out_off[v]; k < out_off[v + 1]; k++) {
                 int64_t e = out_edge[k];
@@ -383,7 +424,7 @@ struct Automaton {
                 seen[v] = 1;
                 o.num(id[v]);
                 o.lit(final_[v] ? " [shape=doublecircle, label=\"" : " [shape=circle, label=\"");
-                o.num(cid[v]);
+                o.num(printed_cid(v));
                 o.lit(": ");
                 o.str(sig_text(v, ", "));
                 o.lit("\"];\n");
@@ -457,7 +498,7 @@ struct Automaton {
         std::vector<int32_t> vals32;
         for (int64_t v : order) {
             ids.push_back((uint32_t)id[v]);
-            cids.push_back(cid[v]);
+            cids.push_back(printed_cid(v));
             fins.push_back(final_[v]);
             for (int c = 0; c < sig_len; c++) sigs.push_back(sig[v * sig_len + c]);
             uint32_t deg = 0;
@@ -741,6 +782,11 @@ int stcsp_automaton_flags(const stcsp_automaton *a, uint8_t *valid, uint8_t *fin
     if (valid) memcpy(valid, g.valid.data(), g.valid.size());
     if (final_flags) memcpy(final_flags, g.final_.data(), g.final_.size());
     if (alive) memcpy(alive, g.ealive.data(), g.ealive.size());
+    return STCSP_OK;
+}
+int stcsp_automaton_order_by_label(stcsp_automaton *a) {
+    if (!a) return STCSP_E_INVALID;
+    a->a.order_by_label();
     return STCSP_OK;
 }
 int stcsp_automaton_renumber(stcsp_automaton *a) {

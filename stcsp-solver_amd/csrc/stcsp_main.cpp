@@ -84,6 +84,7 @@ static int run_once(const Flags &f, bool print_line, double *total) {
     stcsp_automaton_import_flags(a, post.state_valid, post.state_final, post.edge_alive);
     if (f.adv1) printf("adver1: %d; ", post.adver1);
     if (f.adv2) printf("adver2: %d\n", post.adver2);
+    if (f.print_solution || f.binary) stcsp_automaton_order_by_label(a);  // reproducible files whatever the GPU's scheduling
     stcsp_automaton_renumber(a);
     double proc_time = cpu_time() - t_proc;
     if (f.print_solution) stcsp_automaton_write_dot(a, "solutions.dot");

@@ -67,3 +67,43 @@ def test_dot_format_lines(stcsp, RefOracle, tmp_path):
     assert any("-1" in l for l in body)
     n_vals = {len(l.split('"')[1].split(", ")) for l in body if edge.match(l)}
     assert n_vals == {m.n_vars}
+
+
+@pytest.mark.parametrize("name", ["juggling_b4_f5", "digitinvader3", "partialorder_10"])
+def test_label_order_makes_files_reproducible(stcsp, RefOracle, FrontierModel, tmp_path, name):
+    """Two implementations that number states and order edges differently (depth-first restatement
+    vs the frontier algorithm) write byte-identical files after order_by_label()."""
+    m = stcsp.Model.from_name(name)
+    files = []
+    for k, cls in enumerate((RefOracle, FrontierModel)):
+        e = cls(m)
+        r = e.solve()
+        a = e.automaton(r).traverse().order_by_label().renumber()
+        a.write_dot(str(tmp_path / f"{k}.dot"))
+        a.write_binary(str(tmp_path / f"{k}.bin"))
+        files.append(((tmp_path / f"{k}.dot").read_bytes(), (tmp_path / f"{k}.bin").read_bytes()))
+    assert files[0][0] == files[1][0]
+    assert files[0][1] == files[1][1]
+    # and it is still the same automaton
+    assert stcsp.Automaton.read_binary(str(tmp_path / "1.bin")).canonical() == a.canonical()
+
+
+def test_label_order_renumbers_constraint_sets(stcsp, RefOracle, FrontierModel, tmp_path):
+    """Four constraint sets (`@` probe): set ids are printed in the order the output walk meets them."""
+    text = "var x:[0,3]; var y:[0,3]; first x == 0; next x == (x + 1) % 4; y == x@2;"
+    m = stcsp.Model(text=text)
+    outs = []
+    for cls in (RefOracle, FrontierModel):
+        e = cls(m)
+        a = e.automaton(e.solve()).traverse().order_by_label().renumber()
+        p = tmp_path / f"{cls.__name__}.dot"
+        a.write_dot(str(p))
+        outs.append(p.read_text())
+    assert outs[0] == outs[1]
+    import re
+    cids = [int(x) for x in re.findall(r'label="(\d+): ', outs[0])]
+    seen = []
+    for c in cids:
+        if c not in seen:
+            seen.append(c)
+    assert seen == list(range(len(seen))) and len(seen) == 4

@@ -145,3 +145,24 @@ def test_device_postprocess_call_order(stcsp):
         e.postprocess(adversarial=m.n_vars)
     assert ex.value.code == -1
     host_and_device(stcsp, e, r, adv=5)
+
+
+@pytest.mark.parametrize("name", ["juggling_b4_f6", "digitinvader4", "partialorder_11"])
+def test_engine_files_are_reproducible(stcsp, RefOracle, tmp_path, name):
+    """State numbering and edge order on the GPU depend on wavefront scheduling; after
+    order_by_label() the written files do not: identical bytes for different launch batch sizes,
+    and identical to what the depth-first CPU restatement writes."""
+    m = stcsp.Model.from_name(name)
+    blobs = []
+    for k, opts in enumerate(({}, {"batch_nodes": 64}, {"batch_nodes": 1024})):
+        e = stcsp.Engine(m, **opts)
+        r = e.solve()
+        a = e.automaton(r).import_flags(e.postprocess()).order_by_label().renumber()
+        a.write_dot(str(tmp_path / f"{k}.dot"))
+        a.write_binary(str(tmp_path / f"{k}.bin"))
+        blobs.append(((tmp_path / f"{k}.dot").read_bytes(), (tmp_path / f"{k}.bin").read_bytes()))
+    assert blobs[0] == blobs[1] == blobs[2]
+    o = RefOracle(m)
+    ao = o.automaton(o.solve()).traverse().order_by_label().renumber()
+    ao.write_dot(str(tmp_path / "o.dot"))
+    assert (tmp_path / "o.dot").read_bytes() == blobs[0][0]
