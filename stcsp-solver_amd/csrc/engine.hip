@@ -114,6 +114,9 @@ struct stcsp_engine {
     bool dbg_rounds = false;  // STCSP_DEBUG=2: per-launch log (with STCSP_BURST=1 and STCSP_F_PROFILE)
     std::vector<unsigned long long> dbg_nodes;
     std::vector<long long> dbg_open;
+    bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
+    std::vector<uint32_t *> pack_ptr;
+    std::vector<int64_t> pack_count;
     bool sharded = false;    // candidate / commit pipeline (world > 1 or STCSP_F_STEPPED)
     bool persist = false;    // STCSP_PERSIST=1: unsharded solves without budgets use k_persist (experimental)
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
@@ -820,6 +823,7 @@ struct stcsp_engine {
     // ---- sharded stepping
     int expand_local(int64_t *left) {
         if (!begun) return fail(STCSP_E_STATE, "expand_local before begin");
+        packed = false;
         int rc = run_rounds();
         if (rc != STCSP_OK) return rc;
         rc = read_ctl();  // outbox cursors for outbox()
@@ -827,31 +831,44 @@ struct stcsp_engine {
         if (left) *left = truncated ? 0 : (int64_t)h_plan->open_total;
         return STCSP_OK;
     }
+    // The first outbox() call after an expand_local packs the regions of EVERY peer (one kernel per
+    // non-empty peer, one synchronisation), back to back in the pack buffer, so that the driver can hand
+    // the whole buffer to one all-to-all-v; the other calls only read the cached slices.
+    int pack_outboxes() {
+        if (d_pack.n < (size_t)opt.world * R * cand_cap * ctx.CS) HIPCHK(d_pack.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
+        pack_ptr.assign(opt.world, nullptr);
+        pack_count.assign(opt.world, 0);
+        size_t before = 0;
+        for (int peer = 0; peer < opt.world; peer++) {
+            uint32_t total = 0;
+            for (int r = 0; r < R; r++) total += h_ctl[L.cand0 + (peer * R + r) * CST];
+            uint32_t *dst = d_pack.p + before * ctx.CS;
+            if (total)
+                hipLaunchKernelGGL(k_pack, dim3(std::min<uint32_t>(1024, (total * ctx.CS + 255) / 256)), dim3(256), 0, stream,
+                                   d_cand.p + (size_t)peer * R * cand_cap * ctx.CS, cand_cap, ctx.CS, d_ctl.p, L.cand0 + peer * R * CST, dst);
+            pack_ptr[peer] = dst;
+            pack_count[peer] = total;
+            before += total;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        packed = true;
+        return STCSP_OK;
+    }
     int outbox(int peer, void **ptr, int64_t *count) {
         if (peer < 0 || peer >= opt.world) return fail(STCSP_E_INVALID, "peer out of range");
-        uint32_t total = 0;
-        for (int r = 0; r < R; r++) total += h_ctl[L.cand0 + (peer * R + r) * CST];
-        // pack this peer's regions; each peer gets its own slice of the pack buffer
-        if (d_pack.n < (size_t)opt.world * R * cand_cap * ctx.CS) HIPCHK(d_pack.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
-        // peers are packed back to back (peer p starts where p-1 ended), so the driver can hand the
-        // whole buffer to one all-to-all-v without gathering the slices first
-        size_t before = 0;
-        for (int q = 0; q < peer; q++)
-            for (int r = 0; r < R; r++) before += h_ctl[L.cand0 + (q * R + r) * CST];
-        uint32_t *dst = d_pack.p + before * ctx.CS;
-        if (total) {
-            hipLaunchKernelGGL(k_pack, dim3(std::min<uint32_t>(1024, (total * ctx.CS + 255) / 256)), dim3(256), 0, stream,
-                               d_cand.p + (size_t)peer * R * cand_cap * ctx.CS, cand_cap, ctx.CS, d_ctl.p, L.cand0 + peer * R * CST, dst);
-            HIPCHK(hipGetLastError());
+        if (!packed) {
+            int rc = pack_outboxes();
+            if (rc != STCSP_OK) return rc;
         }
-        HIPCHK(hipStreamSynchronize(stream));
-        *ptr = dst;
-        *count = total;
+        *ptr = pack_ptr[peer];
+        *count = pack_count[peer];
         return STCSP_OK;
     }
     int commit(const void *records, int64_t count) {
         if (!begun) return fail(STCSP_E_STATE, "commit before begin");
         // the outbox has been handed over: empty it
+        packed = false;
         HIPCHK(hipMemsetAsync(d_ctl.p + L.cand0, 0, (size_t)(L.edge0 - L.cand0) * sizeof(uint32_t), stream));
         for (int i = L.cand0; i < L.edge0; i++) h_ctl[i] = 0;
         if (count <= 0) {

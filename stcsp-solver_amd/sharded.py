@@ -65,9 +65,10 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
         outs = [engine.outbox(p) for p in range(world)]  # (ptr, record count) per peer
         n_sets = engine.sets_count()
         meta = torch.tensor([c for _, c in outs] + [left, n_sets], dtype=torch.int64, device=comm_dev)
-        allmeta = [torch.empty_like(meta) for _ in range(world)]
-        dist.all_gather(allmeta, meta)
-        allmeta = [m.tolist() for m in allmeta]
+        gathered = torch.empty(world * (world + 2), dtype=torch.int64, device=comm_dev)
+        dist.all_gather_into_tensor(gathered, meta)
+        flat = gathered.tolist()  # one device-to-host copy for the whole table
+        allmeta = [flat[r * (world + 2):(r + 1) * (world + 2)] for r in range(world)]
         sets_now = [m[world + 1] for m in allmeta]
         if sets_now != last_sets:  # somebody met a new constraint set: everyone learns all of them
             blobs = [None] * world
