@@ -148,8 +148,15 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_val
                     case OP_ADD: r = (int)((unsigned)a + (unsigned)b); break;
                     case OP_SUB: r = (int)((unsigned)a - (unsigned)b); break;
                     case OP_MUL: r = (int)((unsigned)a * (unsigned)b); break;
-                    case OP_DIV: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a / b; break;
-                    case OP_MOD: r = (b == 0 || (a == INT_MIN && b == -1)) ? 0 : a % b; break;
+                    case OP_DIV:
+                    case OP_MOD: {
+                        // one division serves both (hipcc expands a 32-bit signed division into ~30
+                        // instructions with a dozen temporaries: two of them set the kernel's VGPR peak)
+                        const bool safe = !(b == 0 || (a == INT_MIN && b == -1));
+                        const int q = safe ? a / b : 0;
+                        r = op == OP_DIV ? q : (safe ? (int)((unsigned)a - (unsigned)q * (unsigned)b) : 0);
+                        break;
+                    }
                     case OP_LT: r = a < b; break;
                     case OP_GT: r = a > b; break;
                     case OP_LE: r = a <= b; break;

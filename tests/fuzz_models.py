@@ -48,8 +48,10 @@ class Gen:
             return f"({a} - {b})"
         if k < 40:
             return f"({a} * {self.r.below(3)})"
-        if k < 46:
+        if k < 44:
             return f"({a} % {2 + self.r.below(2)})"
+        if k < 46:
+            return f"({a} / {1 + self.r.below(3)})"
         if k < 50:
             return f"(abs {a})"
         if k < 78:
