@@ -492,6 +492,9 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
         ItemDesc it{};
         it.type = IT_SMALL;
         it.arity = s;
+        // rows are fetched four at a time (128-bit reads): the table starts on a 4-word boundary
+        // and every run of r1 rows is padded to a multiple of 4 (small_row_stride)
+        while (out.tables.size() & 3) out.tables.push_back(0u);
         it.toff = (int32_t)out.tables.size();
         it.r1 = others.size() > 0 ? size[others[0]] : 1;
         it.r2 = others.size() > 1 ? size[others[1]] : 1;
@@ -512,6 +515,8 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
                         if (holds()) row |= 1u << b0;
                     }
                     out.tables.push_back(row);
+                    if (b1 == it.r1 - 1)
+                        for (int pad = it.r1; pad < small_row_stride(it.r1); pad++) out.tables.push_back(0u);
                 }
         small.push_back(it);
         is_small = true;

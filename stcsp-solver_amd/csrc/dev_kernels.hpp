@@ -7,7 +7,7 @@ namespace stcsp {
 namespace dev {
 // ------------------------------------------------------------------ k_expand (round-based)
 // expand ONE open node (slot `gw` of this round) with one wavefront
-template <int DR, bool L>
+template <int DR, bool L, bool CS>
 __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
     const int r = gw % R, i = gw / R;
     const int take_r = kload(c.plan, (int)(offsetof(Plan, take) / 4) + r);
@@ -69,7 +69,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         hd.seed = rflu(hd.seed);
         hd.expire = rflu(hd.expire);
         const unsigned long long t_p = PHASE_NOW();
-        const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+        const int oc = process_node<DR, L, CS>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
         const bool last = step >= chain || __builtin_amdgcn_s_memtime() - t_slot > chain_cycles;
         const unsigned long long t_c = PHASE_NOW();
         (void)t_p;
@@ -428,7 +428,7 @@ __global__ void k_close_segment(Ctx c) {
 #endif
 // Ctx is read through a pointer (scalar loads on demand): passing it by value kept ~130 SGPRs
 // live/spilled and cost a wavefront of occupancy per SIMD.
-template <int DR, bool L>
+template <int DR, bool L, bool CS>
 __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *__restrict__ cp) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -438,19 +438,19 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
     if ((int)blockIdx.x * 4 >= n_slots) return;
     const unsigned n_working = (unsigned)min((n_slots + 3) / 4, (int)gridDim.x);
-    const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
     const unsigned long long t_k0 = PHASE_NOW();
     (void)t_k0;
-    if (L) {
+    if (img_words) {
         const uint4 *src = (const uint4 *)c.img;
         uint4 *dst = (uint4 *)smem;
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 1 + 63) & ~63);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
-    Img<L> P{L ? (const uint32_t *)smem : c.img};
+    Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
     ExpandArgs a;
     {
         const Plan *p = c.plan;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *_
     const int total_waves = gridDim.x * 4;
     const unsigned long long t_k1 = PHASE_NOW();
     (void)t_k1;
-    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L>(c, a, P, gw, lane, lds_vals, lds_stk);
+    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS>(c, a, P, gw, lane, lds_vals, lds_stk);
     __syncthreads();
 #ifdef STCSP_PHASES
     if (threadIdx.x == 0) {
@@ -598,19 +598,19 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int img_words = L ? ((c.o.words + 3) & ~3) : 0;
+    const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
     const unsigned long long t_k0 = PHASE_NOW();
     (void)t_k0;
-    if (L) {
+    if (img_words) {
         const uint4 *src = (const uint4 *)c.img;
         uint4 *dst = (uint4 *)smem;
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 63) & ~63);
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 1 + 63) & ~63);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
-    Img<L> P{L ? (const uint32_t *)smem : c.img};
+    Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
     const int wid = blockIdx.x * 4 + wib;
     uint32_t *mystack = c.pstack + (size_t)wid * c.pstk_cap * c.NS;
     const CtlLayout L_(c.world);
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
         }
         BranchOut bo;
         LeafOut<DR> lo;
-        const int oc = process_node<DR, L>(c, P, lane, lds_vals, lds_stk, dom, hd, wid + (int)nodes_done, bo, lo);
+        const int oc = process_node<DR, L, false>(c, P, lane, lds_vals, lds_stk, dom, hd, wid + (int)nodes_done, bo, lo);
         nodes_done++;
         if (oc == OC_FAIL) {
             have = false;

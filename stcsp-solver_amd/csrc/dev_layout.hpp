@@ -63,6 +63,7 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
         arr_off, words;
+    int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };
 
 struct Ctx {
@@ -73,6 +74,7 @@ struct Ctx {
     // user arrays (potentially large) stay in global memory
     const uint32_t *img;
     ImgOff o;
+    int stage_words;  // image words every workgroup copies into LDS: o.words (whole image), a prefix of whole hot sections, or 0
     const int *code;
     const int *arr_data;
     unsigned long long *slots;

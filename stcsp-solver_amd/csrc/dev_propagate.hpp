@@ -10,10 +10,17 @@ namespace dev {
 // u(): wave-uniform read (scalar load / broadcast LDS read), v(): per-lane read.
 template <bool L>
 struct Img {
-    const uint32_t *p;
-    __device__ __forceinline__ int v(int off) const { return (int)p[off]; }
-    __device__ __forceinline__ uint4 v4(int off) const { return *(const uint4 *)(p + off); }  // off % 4 == 0
-    __device__ __forceinline__ int u(int off) const;
+    const uint32_t *p;    // the image in global memory
+    const uint32_t *lds;  // its staged copy: the whole image when L, else the first `nlds` words
+    int nlds;
+    __device__ __forceinline__ int v(int off) const;
+    __device__ __forceinline__ uint4 v4(int off) const;  // off % 4 == 0 (sections and records are 16-byte aligned)
+    __device__ __forceinline__ int u(int off) const;     // wave-uniform offset -> scalar value
+    // the same for the cold sections (cons, scope, strides, items, tables), which are never part of a
+    // staged prefix: no boundary test on the paths that read them most
+    __device__ __forceinline__ int vc(int off) const;
+    __device__ __forceinline__ uint4 v4c(int off) const;
+    __device__ __forceinline__ int uc(int off) const;
 };
 // The compiled program (bytecode, descriptors, tables) is read-only for the lifetime of a launch
 // and indexed wave-uniformly: reading it through the constant address space makes hipcc emit
@@ -23,9 +30,34 @@ __device__ __forceinline__ int kload(const void *base, int idx) {
     return ((kptr)(const __attribute__((address_space(1))) int *)base)[idx];
 }
 template <>
-__device__ __forceinline__ int Img<true>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)p[off]); }
+__device__ __forceinline__ int Img<true>::v(int off) const { return (int)lds[off]; }
 template <>
-__device__ __forceinline__ int Img<false>::u(int off) const { return kload(p, off); }
+__device__ __forceinline__ uint4 Img<true>::v4(int off) const { return *(const uint4 *)(lds + off); }
+template <>
+__device__ __forceinline__ int Img<true>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+template <>
+__device__ __forceinline__ int Img<true>::vc(int off) const { return (int)lds[off]; }
+template <>
+__device__ __forceinline__ uint4 Img<true>::v4c(int off) const { return *(const uint4 *)(lds + off); }
+template <>
+__device__ __forceinline__ int Img<true>::uc(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+// image larger than the LDS budget: a prefix of hot sections is staged, the rest is read from HBM/L2
+template <>
+__device__ __forceinline__ int Img<false>::v(int off) const { return off < nlds ? (int)lds[off] : (int)p[off]; }
+template <>
+__device__ __forceinline__ uint4 Img<false>::v4(int off) const {
+    return off < nlds ? *(const uint4 *)(lds + off) : *(const uint4 *)(p + off);
+}
+template <>
+__device__ __forceinline__ int Img<false>::u(int off) const {
+    return off < nlds ? __builtin_amdgcn_readfirstlane((int)lds[off]) : kload(p, off);
+}
+template <>
+__device__ __forceinline__ int Img<false>::vc(int off) const { return (int)p[off]; }
+template <>
+__device__ __forceinline__ uint4 Img<false>::v4c(int off) const { return *(const uint4 *)(p + off); }
+template <>
+__device__ __forceinline__ int Img<false>::uc(int off) const { return kload(p, off); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -71,7 +103,7 @@ struct Dom {
 struct WaveStats {
     unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
     unsigned long long cyc_sweep = 0, cyc_wave = 0;
-    unsigned long long evals = 0;
+    unsigned long long evals = 0;   // wave-uniform: rows looked at by all lanes (sweeps) + tuples of wavefront revisions
 };
 
 // Evaluate one constraint program on this lane's tuple (the role of solverValidateRe,
@@ -208,14 +240,14 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
-    if (lane < s) var = G.v(c.o.scope + C.scope_off + lane);
+    if (lane < s) var = G.vc(c.o.scope + C.scope_off + lane);
     uint32_t D = dom.gather(p * c.N + var);
     if (lane >= s) D = 0;
     const int n = lane < s ? __popc(D) : 1;
     if (__ballot(lane < s && n == 0)) return false;
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
     const bool use_bitmap = C.bitmap_off >= 0;
-    const int mystride = (use_bitmap && lane < s) ? G.v(c.o.strides + C.stride_off + lane) : 0;
+    const int mystride = (use_bitmap && lane < s) ? G.vc(c.o.strides + C.stride_off + lane) : 0;
 
     // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
     // multiply to <= 64 are enumerated ACROSS LANES (lane index = mixed-radix tuple index), the rest
@@ -330,7 +362,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
                 const int j = __ffsll((long long)hm) - 1;
                 bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
             }
-            res = active ? (int)(((uint32_t)G.v(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
+            res = active ? (int)(((uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
         } else {
             res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
         }
@@ -407,7 +439,7 @@ template <bool L>
 __device__ __forceinline__ void load_con(const Ctx &c, const Img<L> &P, int idx, ConDesc &C) {
     int *dst = (int *)&C;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = P.u(c.o.cons + idx * (int)(sizeof(ConDesc) / 4) + i);
+    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = P.uc(c.o.cons + idx * (int)(sizeof(ConDesc) / 4) + i);
 }
 
 __device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
@@ -462,7 +494,7 @@ __device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_ba
 // node like solverSolveRe does: failed / branch / leaf (or "miss": a leaf whose constraint-set
 // translation the host has not provided yet). Outputs stay in registers; the callers (the
 // round-based k_expand and the persistent k_persist) decide where children and leaves go.
-template <int DR, bool L>
+template <int DR, bool L, bool CS>
 __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, Dom<DR> &dom,
                             const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
     const CtlLayout L_(c.world);
@@ -504,6 +536,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         int idx = q * 64 + lane;
         if (idx < c.NK) ldom[idx] = (int)dom.r[q];
     }
+    if (lane == 0) ldom[c.NK] = 0;  // rows examined by the sweeps of this node (statistics)
     while (consistent) {
         if (__ballot((dirtyw & smallmask) != 0)) {
             const unsigned long long t_sw = PHASE_NOW();
@@ -512,12 +545,49 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
             __builtin_amdgcn_wave_barrier();
             bool lfail = false;
             ws.sweeps++;
-            const int npass = (S.nsmall + 63) >> 6;
+            // Sets with many small items (the synthetic 64 x 32 family: 1,216) have their dirty items
+            // scattered over the item index space -- ~120 dirty per sweep in 19 blocks of 64, six
+            // busy lanes per pass. There the dirty bits are compacted first: lane k of pass t takes
+            // the (64 t + k)-th dirty item (prefix counts of the per-lane dirty words, a 6-step
+            // search over them with ds_bpermute), so a sweep needs ceil(dirty / 64) passes.
+            const bool compact = CS && S.nsmall > kCompactSweepItems;  // CS: separate kernel, the search costs ~15 VGPRs
+            uint32_t dsm = 0;
+            int excl = 0, total_dirty = 0;
+            if (compact) {
+                dsm = lane < S.iw ? (dirtyw & smallmask) : 0u;
+                const int cnt = __popc(dsm);
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                excl = incl - cnt;
+                total_dirty = (int)rdlane((uint32_t)incl, 63);
+            }
+            const int npass = compact ? (total_dirty + 63) >> 6 : (S.nsmall + 63) >> 6;
             for (int t = 0; t < npass; t++) {
-                const int item = t * 64 + lane;
-                const uint32_t dw0 = rdlane(dirtyw, (2 * t) & 63), dw1 = rdlane(dirtyw, (2 * t + 1) & 63);
-                const uint32_t dw = lane < 32 ? dw0 : dw1;
-                const bool isd = item < S.nsmall && ((dw >> (item & 31)) & 1u);
+                int item;
+                bool isd;
+                if (compact) {
+                    const int k = t * 64 + lane;
+                    int w = 0;  // the last lane whose exclusive prefix is <= k owns the k-th dirty bit
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        const int cand = w + step;
+                        const int e = __shfl(excl, cand & 63, 64);
+                        if (cand < 64 && e <= k) w = cand;
+                    }
+                    const uint32_t word = (uint32_t)__shfl((int)dsm, w, 64);
+                    const int first = __shfl(excl, w, 64);
+                    isd = k < total_dirty;
+                    item = isd ? w * 32 + select_kth_fast(word, k - first) : 0;
+                } else {
+                    item = t * 64 + lane;
+                    const uint32_t dw0 = rdlane(dirtyw, (2 * t) & 63), dw1 = rdlane(dirtyw, (2 * t + 1) & 63);
+                    const uint32_t dw = lane < 32 ? dw0 : dw1;
+                    isd = item < S.nsmall && ((dw >> (item & 31)) & 1u);
+                }
                 unsigned long long dmask = __ballot(isd);
                 if (!dmask) continue;
                 ws.revs += (unsigned)__popcll(dmask);
@@ -562,26 +632,51 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                         if (it.arity < 4) D3 = 1u;
                         uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
                         const int tab = c.o.tables + it.toff;
-                        unsigned nev = 0;
+                        unsigned nev = 0;  // table rows this lane looks at
+                        const int r1p = (it.r1 + 3) & ~3;  // small_row_stride: rows come four per 128-bit read
                         for (uint32_t m3 = D3; m3; m3 &= m3 - 1) {
                             const int b3 = __ffs((int)m3) - 1;
                             for (uint32_t m2 = D2; m2; m2 &= m2 - 1) {
                                 const int b2 = __ffs((int)m2) - 1;
-                                const int base = it.r1 * (b2 + it.r2 * b3);
-                                for (uint32_t m1 = D1; m1; m1 &= m1 - 1) {
-                                    const int b1 = __ffs((int)m1) - 1;
-                                    const uint32_t row = (uint32_t)P.v(tab + base + b1) & D0;
-                                    nev++;
-                                    if (row) {
-                                        s0 |= row;
-                                        s1 |= 1u << b1;
-                                        s2 |= 1u << b2;
-                                        s3 |= 1u << b3;
+                                const int base = tab + r1p * (b2 + it.r2 * b3);
+                                uint32_t any = 0;
+                                for (int c4 = 0; c4 < r1p; c4 += 8) {  // eight rows per trip, two independent reads
+                                    const uint32_t nib = (D1 >> c4) & 0xffu;
+                                    if (!nib) continue;
+                                    const bool second = (nib >> 4) != 0u;  // implies c4 + 4 < r1p
+                                    const uint4 ra = P.v4c(base + c4);
+                                    uint4 rb = make_uint4(0u, 0u, 0u, 0u);
+                                    if (second) rb = P.v4c(base + c4 + 4);
+                                    uint32_t got = 0;
+                                    {
+                                        const uint32_t rows[4] = {ra.x, ra.y, ra.z, ra.w};
+#pragma unroll
+                                        for (int k = 0; k < 4; k++) {
+                                            const uint32_t r = ((nib >> k) & 1u) ? (rows[k] & D0) : 0u;
+                                            s0 |= r;
+                                            got |= (r ? 1u : 0u) << k;
+                                        }
                                     }
+                                    if (second) {
+                                        const uint32_t rows[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+                                        for (int k = 0; k < 4; k++) {
+                                            const uint32_t r = ((nib >> (4 + k)) & 1u) ? (rows[k] & D0) : 0u;
+                                            s0 |= r;
+                                            got |= (r ? 1u : 0u) << (4 + k);
+                                        }
+                                    }
+                                    nev += (unsigned)__popc(nib);
+                                    s1 |= got << c4;
+                                    any |= got;
+                                }
+                                if (any) {
+                                    s2 |= 1u << b2;
+                                    s3 |= 1u << b3;
                                 }
                             }
                         }
-                        ws.evals += nev;
+                        if (nev) atomicAdd((unsigned *)&ldom[c.NK], nev);  // statistics: one LDS add, nobody waits for it
                         if (s0 == 0) lfail = true;
                         if (s0 != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], s0);
                         if (it.arity > 1 && s1 != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], s1);
@@ -627,7 +722,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         int item = wl * 32 + b;
         if (lane == wl) dirtyw &= ~(1u << b);
         const int ibase = c.o.items + (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
-        const int ipoint = P.u(ibase + 1), icon = P.u(ibase + 2);
+        const int ipoint = P.uc(ibase + 1), icon = P.uc(ibase + 2);
         ConDesc C;
         load_con<L>(c, P, icon, C);
         consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc);
@@ -638,6 +733,8 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         }
     }
     if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ws.evals += (unsigned)ldom[c.NK];
         add_stats(c, gw, ST_NODES, 1);
         add_stats(c, gw, ST_REVS, ws.revs);
         add_stats(c, gw, ST_EVALS, ws.evals);

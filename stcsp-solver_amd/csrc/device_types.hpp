@@ -16,6 +16,7 @@ namespace stcsp {
 
 constexpr int kRegions = 32;        // cursor shards per segment (spreads allocation atomics)
 constexpr int kMaxDomRegs = 4;      // N*K <= 64 * kMaxDomRegs words live in VGPRs, lane-striped
+constexpr int kCompactSweepItems = 128;  // sets with more small items than this sweep over a compacted dirty list
 constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revision (2^6 = 64)
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
@@ -85,6 +86,9 @@ struct ItemDesc {
     int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2
     int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal ; SMALL: number of table rows
 };
+
+// IT_SMALL tables: row (b1, b2, b3) lives at toff + small_row_stride(r1) * (b2 + r2 * b3) + b1
+inline constexpr int small_row_stride(int r1) { return (r1 + 3) & ~3; }
 
 // What the lane-per-item sweep needs of an ItemDesc, packed into one 16-byte record so that a
 // lane fetches its item with a single 128-bit LDS read:

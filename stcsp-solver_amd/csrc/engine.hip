@@ -114,6 +114,7 @@ struct stcsp_engine {
     bool dbg_rounds = false;  // STCSP_DEBUG=2: per-launch log (with STCSP_BURST=1 and STCSP_F_PROFILE)
     std::vector<unsigned long long> dbg_nodes;
     std::vector<long long> dbg_open;
+    bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true>
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
     std::vector<uint32_t *> pack_ptr;
     std::vector<int64_t> pack_count;
@@ -210,17 +211,17 @@ struct stcsp_engine {
             int w = mgr.ub[v] - mgr.lb[v] + 1;
             init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
         }
+        // Hot sections first (every node reads them; the lane-per-item sweep reads `sweep` and
+        // `itemrows` with per-lane addresses), then the ones only wavefront revisions and leaves of
+        // new sets touch, the (potentially big) tables last. When the whole image does not fit the
+        // LDS budget, a prefix of whole hot sections is staged instead (hot_end[] = candidate cuts).
+        std::vector<int> hot_end;
         o.sets = put(prog.sets.data(), prog.sets.size() * sizeof(SetDesc));
-        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
-        o.scope = put(prog.scope.data(), prog.scope.size() * 4);
-        o.strides = put(prog.strides.data(), prog.strides.size() * 4);
-        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
         {
             std::vector<uint32_t> sweep(prog.items.size() * 4);
             for (size_t i = 0; i < prog.items.size(); i++) pack_sweep_item(prog.items[i], &sweep[i * 4]);
             o.sweep = put(sweep.data(), sweep.size() * 4);
         }
-        o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
         o.var_lb = put(mgr.lb.data(), mgr.lb.size() * 4);
         o.var_init = put(init.data(), init.size() * 4);
         o.sig_vars = put(mgr.sig_vars.data(), mgr.sig_vars.size() * 4);
@@ -229,6 +230,16 @@ struct stcsp_engine {
         o.trans = put(prog.trans.data(), prog.trans.size() * sizeof(TransDesc));
         o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
         o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
+        while (img.size() & 3) img.push_back(0u);
+        hot_end.push_back((int)img.size());
+        o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
+        while (img.size() & 3) img.push_back(0u);
+        hot_end.push_back((int)img.size());
+        o.hot_words = (int)img.size();
+        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
+        o.scope = put(prog.scope.data(), prog.scope.size() * 4);
+        o.strides = put(prog.strides.data(), prog.strides.size() * 4);
+        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
         o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
         while (img.size() & 3) img.push_back(0u);
         o.words = (int)img.size();
@@ -238,13 +249,17 @@ struct stcsp_engine {
         ctx.o = o;
         ctx.code = d_code.p;
         ctx.nsets = (int)prog.sets.size();
+        compact_sweeps = false;
+        for (const SetDesc &sd : prog.sets) compact_sweeps = compact_sweeps || sd.nsmall > kCompactSweepItems;
         ctx.stack_slots = prog.max_stack + 2;
-        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 63) & ~63)) * sizeof(int);
+        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 1 + 63) & ~63)) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
         if (const char *ev = getenv("STCSP_IMG_LDS")) img_in_lds = img_in_lds && atoi(ev) != 0;  // tuning switch
-        lds_bytes = scratch + (img_in_lds ? (size_t)o.words * 4 : 0);
+        ctx.stage_words = img_in_lds ? o.words : 0;
+        lds_bytes = scratch + (size_t)ctx.stage_words * 4;
+        const bool try_prefix = !img_in_lds && !(getenv("STCSP_IMG_LDS") && atoi(getenv("STCSP_IMG_LDS")) == 0);
         // Grid = exactly the workgroups that are resident at once: wavefronts take node slots with
         // a static grid stride, so a workgroup that has to wait for a free CU slot would start its
         // share only when another one has finished all of its own (a 2x tail).
@@ -253,18 +268,33 @@ struct stcsp_engine {
             hipError_t e;
             const void *fn;
             switch (DR) {
-                case 1: fn = img_in_lds ? (const void *)k_expand<1, true> : (const void *)k_expand<1, false>; break;
-                case 2: fn = img_in_lds ? (const void *)k_expand<2, true> : (const void *)k_expand<2, false>; break;
-                default: fn = img_in_lds ? (const void *)k_expand<4, true> : (const void *)k_expand<4, false>; break;
+                case 1: fn = expand_fn<1>(); break;
+                case 2: fn = expand_fn<2>(); break;
+                default: fn = expand_fn<4>(); break;
             }
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
+            if (try_prefix && e == hipSuccess && per_cu > 0) {
+                // the longest prefix of whole hot sections that costs no resident workgroup: the kernel's
+                // registers allow per_cu workgroups, each may use 160 KB / per_cu of LDS (<= 64 KB)
+                const size_t budget = std::min<size_t>((size_t)160 * 1024 / (size_t)per_cu, (size_t)64 * 1024);
+                for (int cut : hot_end)
+                    if (scratch + (size_t)cut * 4 <= budget) ctx.stage_words = cut;
+                if (ctx.stage_words) {
+                    int with_prefix = 0;
+                    const size_t bytes = scratch + (size_t)ctx.stage_words * 4;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with_prefix, fn, 256, bytes) == hipSuccess && with_prefix >= per_cu)
+                        lds_bytes = bytes;
+                    else
+                        ctx.stage_words = 0;
+                }
+            }
             hipDeviceProp_t prop;
             if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
                 max_blocks = per_cu * prop.multiProcessorCount;
             if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
             if (getenv("STCSP_DEBUG"))
-                fprintf(stderr, "[engine] image %d words (%s), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
-                        o.words, img_in_lds ? "in LDS" : "global", scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
+                fprintf(stderr, "[engine] image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
+                        o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
             // the persistent kernel has its own register footprint
             switch (DR) {
                 case 1: fn = img_in_lds ? (const void *)k_persist<1, true> : (const void *)k_persist<1, false>; break;
@@ -555,12 +585,22 @@ struct stcsp_engine {
         return STCSP_OK;
     }
 
+    // kernel variant: whole image in LDS or not, compacted sweeps (sets with > kCompactSweepItems small items) or not
+    template <int DRT>
+    const void *expand_fn() const {
+        if (img_in_lds) return compact_sweeps ? (const void *)k_expand<DRT, true, true> : (const void *)k_expand<DRT, true, false>;
+        return compact_sweeps ? (const void *)k_expand<DRT, false, true> : (const void *)k_expand<DRT, false, false>;
+    }
     template <int DRT>
     void launch_expand() {
-        if (img_in_lds)
-            hipLaunchKernelGGL((k_expand<DRT, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
-        else
-            hipLaunchKernelGGL((k_expand<DRT, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
+        const Ctx *cp = (const Ctx *)d_ctx.p;
+        if (img_in_lds) {
+            if (compact_sweeps) hipLaunchKernelGGL((k_expand<DRT, true, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+            else hipLaunchKernelGGL((k_expand<DRT, true, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+        } else {
+            if (compact_sweeps) hipLaunchKernelGGL((k_expand<DRT, false, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+            else hipLaunchKernelGGL((k_expand<DRT, false, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+        }
     }
 
     int service_misses() {

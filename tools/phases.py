@@ -6,6 +6,6 @@ lib = C.CDLL(str(st.CSRC / "libstcsp_hip_phases.so")); st.bind_engine_api(lib)
 class E(st.EngineBase):
     def __init__(self, m, **o): super().__init__(lib, m, **o)
 for name in sys.argv[1:] or ["partialorder_14"]:
-    m = st.Model.from_name(name)
-    e = E(m, flags=st.F_NO_EXPORT); e.solve(); e.solve()
+    m = st.Model(text=st.instances.synthetic(64, 32, 602, 6, 20261003)) if name == "synth" else st.Model.from_name(name)
+    e = E(m, flags=st.F_NO_EXPORT, time_limit_s=2.0 if name == "synth" else 0.0); e.solve(); e.solve()
     c = e.counters(); print(name, "nodes", c.search_nodes, "search s", c.seconds_search)
