@@ -640,30 +640,28 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                                 const int b2 = __ffs((int)m2) - 1;
                                 const int base = tab + r1p * (b2 + it.r2 * b3);
                                 uint32_t any = 0;
-                                for (int c4 = 0; c4 < r1p; c4 += 8) {  // eight rows per trip, two independent reads
-                                    const uint32_t nib = (D1 >> c4) & 0xffu;
+                                // NQ 128-bit reads (4 rows each) in flight per trip; the wide-block kernels
+                                // (DR = 4: big models, tables in HBM) have the registers for four
+                                constexpr int NQ = DR >= 4 ? 4 : 2;
+                                for (int c4 = 0; c4 < r1p; c4 += 4 * NQ) {
+                                    const uint32_t nib = (D1 >> c4) & ((1u << (4 * NQ)) - 1u);
                                     if (!nib) continue;
-                                    const bool second = (nib >> 4) != 0u;  // implies c4 + 4 < r1p
-                                    const uint4 ra = P.v4c(base + c4);
-                                    uint4 rb = make_uint4(0u, 0u, 0u, 0u);
-                                    if (second) rb = P.v4c(base + c4 + 4);
-                                    uint32_t got = 0;
-                                    {
-                                        const uint32_t rows[4] = {ra.x, ra.y, ra.z, ra.w};
+                                    uint4 rr[NQ];
 #pragma unroll
-                                        for (int k = 0; k < 4; k++) {
-                                            const uint32_t r = ((nib >> k) & 1u) ? (rows[k] & D0) : 0u;
-                                            s0 |= r;
-                                            got |= (r ? 1u : 0u) << k;
-                                        }
+                                    for (int g = 0; g < NQ; g++) {  // a non-empty group of D1 bits implies c4 + 4 g < r1p
+                                        rr[g] = make_uint4(0u, 0u, 0u, 0u);
+                                        if (g == 0 || ((nib >> (4 * g)) & 15u)) rr[g] = P.v4c(base + c4 + 4 * g);
                                     }
-                                    if (second) {
-                                        const uint32_t rows[4] = {rb.x, rb.y, rb.z, rb.w};
+                                    uint32_t got = 0;
+#pragma unroll
+                                    for (int g = 0; g < NQ; g++) {
+                                        if (g > 0 && !((nib >> (4 * g)) & 15u)) continue;
+                                        const uint32_t rows[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};
 #pragma unroll
                                         for (int k = 0; k < 4; k++) {
-                                            const uint32_t r = ((nib >> (4 + k)) & 1u) ? (rows[k] & D0) : 0u;
+                                            const uint32_t r = ((nib >> (4 * g + k)) & 1u) ? (rows[k] & D0) : 0u;
                                             s0 |= r;
-                                            got |= (r ? 1u : 0u) << (4 + k);
+                                            got |= (r ? 1u : 0u) << (4 * g + k);
                                         }
                                     }
                                     nev += (unsigned)__popc(nib);
@@ -700,10 +698,21 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 if (__ballot(idx < c.NK && nd == 0)) consistent = false;
                 unsigned long long cm = __ballot(nd != dom.r[q]);
                 dom.r[q] = nd;
-                while (cm) {
-                    int l = __ffsll((long long)cm) - 1;
+                while (cm) {  // four changed words per trip: their dirty rows are independent reads
+                    const int l0 = __ffsll((long long)cm) - 1;
                     cm &= cm - 1;
-                    if (lane < S.iw) dirtyw |= (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (q * 64 + l) * S.iw + lane);
+                    const int l1 = cm ? __ffsll((long long)cm) - 1 : l0;
+                    cm &= cm - 1;
+                    const int l2 = cm ? __ffsll((long long)cm) - 1 : l0;
+                    cm &= cm - 1;
+                    const int l3 = cm ? __ffsll((long long)cm) - 1 : l0;
+                    cm &= cm - 1;
+                    if (lane < S.iw) {
+                        const int rows = c.o.itemrows + S.itemrows_off + lane;
+                        const uint32_t r0 = (uint32_t)P.v(rows + (q * 64 + l0) * S.iw), r1 = (uint32_t)P.v(rows + (q * 64 + l1) * S.iw);
+                        const uint32_t r2 = (uint32_t)P.v(rows + (q * 64 + l2) * S.iw), r3 = (uint32_t)P.v(rows + (q * 64 + l3) * S.iw);
+                        dirtyw |= r0 | r1 | r2 | r3;
+                    }
                 }
             }
             if (++guard > (1u << 20)) {
