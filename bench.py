@@ -91,11 +91,10 @@ def main():
 
     def one_step():
         if world == 1:
-            eng.solve()
-        else:
-            from importlib import import_module
-            sh = import_module("stcsp-solver_amd.sharded")
-            sh.solve_sharded(eng, rank, world, dev)
+            return eng.solve().counters  # the engine reads its counters once, at the end of the solve
+        from importlib import import_module
+        sh = import_module("stcsp-solver_amd.sharded")
+        sh.solve_sharded(eng, rank, world, dev)
         return eng.counters()
 
     def barrier():
