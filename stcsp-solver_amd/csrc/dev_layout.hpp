@@ -68,6 +68,7 @@ struct ImgOff {
 
 struct Ctx {
     int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
+    int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
     int sharded;  // leaves emit successor candidates for their owner (world > 1, or STCSP_F_STEPPED) instead of committing in place
     // the compiled program: one contiguous image of 32-bit words (sections at the offsets in `o`),
     // staged into LDS by every workgroup of k_expand when it fits; the bytecode and the

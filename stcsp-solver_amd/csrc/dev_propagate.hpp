@@ -310,7 +310,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield
     // the same automaton.
     {
-        const unsigned long long budget = use_bitmap ? kBudgetBitmapIters : kBudgetCodeIters;
+        const unsigned long long budget = (unsigned long long)(unsigned)(use_bitmap ? c.budget_bitmap : c.budget_code);
         unsigned long long total_hi = 1;
         for (unsigned long long hm = highmask; hm && total_hi <= budget; hm &= hm - 1)
             total_hi *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)hm) - 1);

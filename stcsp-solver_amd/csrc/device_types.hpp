@@ -22,7 +22,7 @@ constexpr int kMaxScope = 64;       // scope variables per constraint (one lane 
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
 constexpr unsigned long long kBudgetBitmapIters = 4096;  // odometer steps a bitmap revision may take
-constexpr unsigned long long kBudgetCodeIters = 256;     // ... and an interpreted one
+constexpr unsigned long long kBudgetCodeIters = 32;      // ... and an interpreted one
 constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
 constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap compiled per constraint

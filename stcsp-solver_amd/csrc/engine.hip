@@ -345,6 +345,10 @@ struct stcsp_engine {
         ctx.ES = edge_stride(N);
         ctx.world = opt.world;
         ctx.sharded = sharded ? 1 : 0;
+        ctx.budget_bitmap = (int)kBudgetBitmapIters;
+        ctx.budget_code = (int)kBudgetCodeIters;
+        if (const char *ev = getenv("STCSP_BUDGET_BITMAP")) ctx.budget_bitmap = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_BUDGET_CODE")) ctx.budget_code = std::max(1, atoi(ev));
         ctx.rank = opt.rank;
         DR = (N * K + 63) / 64;
         if (DR == 3) DR = 4;
