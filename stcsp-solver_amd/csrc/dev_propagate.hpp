@@ -102,7 +102,7 @@ struct Dom {
 #endif
 struct WaveStats {
     unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
-    unsigned long long cyc_sweep = 0, cyc_wave = 0;
+    unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0;
     unsigned long long evals = 0;   // wave-uniform: rows looked at by all lanes (sweeps) + tuples of wavefront revisions
 };
 
@@ -237,6 +237,8 @@ __device__ __forceinline__ int small_div(int x, int d) {
 template <int DR, bool L>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
                              int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc) {
+    const unsigned long long t_rv0 = PHASE_NOW();
+    (void)t_rv0;
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
@@ -320,6 +322,8 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             return true;
         }
     }
+    const unsigned long long t_rv1 = PHASE_NOW();
+    (void)t_rv1;
     bool hit = false;   // pair lanes: this (low var, digit) has a support
     uint32_t hs = 0;    // scope lanes (high vars): supported value bits
     int digit_h = 0;    // scope lanes (high vars): odometer digit
@@ -339,46 +343,29 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     unsigned long long iters = 0;
     int stage_a_left = highmask ? maxn : 1;
     bool stage_b = false;
-    for (;;) {
+    // next block of tuples: stage A probes, then (with high variables) the all-zero odometer block,
+    // then the odometer in order. false = the product is exhausted.
+    auto next_block = [&]() -> bool {
         if (stage_a_left > 0) {
             if (is_high) {
-                int it = maxn - stage_a_left;
+                const int it = maxn - stage_a_left;
                 curbit = select_kth_fast(D, it - n * small_div(it, n));
                 curval = vlb + curbit;
             }
             stage_a_left--;
-        } else if (!stage_b) {
-            stage_b = true;  // first exhaustive tuple block: all high digits 0
+            return true;
+        }
+        if (!highmask) return false;  // no high variables: the lanes covered the whole product in one block
+        if (!stage_b) {
+            stage_b = true;
             if (is_high) {
                 digit_h = 0;
                 curbit = __ffs((int)D) - 1;
                 curval = vlb + curbit;
             }
+            return true;
         }
-        int res;
-        if (use_bitmap) {
-            int bit = lane_part + base_sum;
-            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
-                const int j = __ffsll((long long)hm) - 1;
-                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
-            }
-            res = active ? (int)(((uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
-        } else {
-            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
-        }
-        ws.evals += nact;
-        const unsigned long long sm = __ballot(active && res != 0);
-        if (sm) {
-            any_sat = true;
-            if (pairlane && (M & sm)) hit = true;
-            if (is_high) hs |= 1u << curbit;
-        }
-        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
-        if (stage_a_left > 0) continue;
-        if (!highmask) break;  // no high variables: the lanes covered the whole product
-        if (!stage_b) continue;
-        // advance the odometer (wave-uniform carry chain over the high variables)
-        bool carry = true;
+        bool carry = true;  // advance the odometer (wave-uniform carry chain over the high variables)
         for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
             const int j = __ffsll((long long)hm) - 1;
             int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
@@ -393,12 +380,59 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
                 curval = vlb + curbit;
             }
         }
-        if (carry) break;  // wrapped around: product exhausted
+        return !carry;
+    };
+    // tuple-bitmap lookups are pipelined one block deep: the word of block i+1 is requested before
+    // block i's answer is used (the bitmaps of large models live in HBM/L2, ~2 k cycles away)
+    auto bitmap_index = [&]() -> int {
+        int bit = lane_part + base_sum;
+        for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+            const int j = __ffsll((long long)hm) - 1;
+            bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
+        }
+        return bit;
+    };
+    next_block();  // the first block always exists
+    int bit_cur = 0;
+    uint32_t word_cur = 0;
+    if (use_bitmap) {
+        bit_cur = bitmap_index();
+        word_cur = active ? (uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit_cur >> 5)) : 0u;
+    }
+    for (;;) {
+        const int curbit_cur = curbit;  // the block whose answer is consumed in this trip
+        int res, bit_nxt = 0;
+        uint32_t word_nxt = 0;
+        bool more;
+        if (use_bitmap) {
+            more = next_block();
+            if (more) {
+                bit_nxt = bitmap_index();
+                word_nxt = active ? (uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit_nxt >> 5)) : 0u;
+            }
+            res = (int)((word_cur >> (bit_cur & 31)) & 1u);
+        } else {
+            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+            more = next_block();
+        }
+        ws.evals += nact;
+        const unsigned long long sm = __ballot(active && res != 0);
+        if (sm) {
+            any_sat = true;
+            if (pairlane && (M & sm)) hit = true;
+            if (is_high) hs |= 1u << curbit_cur;
+        }
+        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
+        if (!more) break;  // product exhausted
         if (++iters > (1ull << 22)) {
             if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             return false;
         }
+        bit_cur = bit_nxt;
+        word_cur = word_nxt;
     }
+    const unsigned long long t_rv2 = PHASE_NOW();
+    (void)t_rv2;
     // --- write back. No satisfying tuple at all: wipe-out. Otherwise singletons are supported by
     // construction and only the enumerated / stepped variables can lose values.
     if (!any_sat) return false;
@@ -426,6 +460,11 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
     // its own changes (supports are whole tuples of surviving values)
     if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+#ifdef STCSP_PHASES
+    ws.cyc_rv_setup += t_rv1 - t_rv0;
+    ws.cyc_rv_loop += t_rv2 - t_rv1;
+    ws.cyc_rv_wb += PHASE_NOW() - t_rv2;
+#endif
     return true;
 }
 
@@ -753,6 +792,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
 #ifdef STCSP_PHASES
         add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
         add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
+        add_stats(c, gw, ST_CYC_RV_SETUP, ws.cyc_rv_setup);
+        add_stats(c, gw, ST_CYC_RV_LOOP, ws.cyc_rv_loop);
+        add_stats(c, gw, ST_CYC_RV_WB, ws.cyc_rv_wb);
 #endif
     }
     if (!consistent) {
