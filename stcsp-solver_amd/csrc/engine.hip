@@ -94,6 +94,9 @@ struct stcsp_engine {
     CtlLayout L{1};
     size_t lds_bytes = 0;
     int chunk_r = 0;  // max nodes taken per region per launch
+    int chunk_r0 = 0;  // ... as configured (an automatic batch may shrink chunk_r during a solve)
+    bool auto_batch = true;
+    size_t arena_soft_words = 0;
     // expansions per slot and launch (expand_node): chain_small while a round has <= chain_thresh
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
     // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). STCSP_CHAIN_SMALL / _BIG /
@@ -357,8 +360,19 @@ struct stcsp_engine {
         rc = upload_program();
         if (rc != STCSP_OK) return rc;
         // pools
-        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : 65536;
-        chunk_r = std::max(1, (batch + R - 1) / R);
+        // Nodes taken per launch. The default is large -- a round costs ~20 us whatever its size and
+        // partialorder_18 runs 46 % faster with 1 M than with 64 k -- and adapts downwards when the
+        // frontier arena passes its soft limit (explosive searches: memory ~ depth x batch). Sharded
+        // engines keep 64 k (their outbox is sized by the batch for every peer).
+        auto_batch = opt.batch_nodes <= 0;
+        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : (sharded ? 65536 : 262144);
+        if (const char *ev = getenv("STCSP_BATCH")) if (atoi(ev) > 0 && auto_batch) batch = atoi(ev);
+        {
+            size_t free_b = 0, total_b = 0;
+            arena_soft_words = ((size_t)8 << 30) / 4;  // 8 GiB
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 16 > ((size_t)1 << 30)) arena_soft_words = std::min(arena_soft_words * 4, free_b / 16 / 4 * 4);
+        }
+        chunk_r = chunk_r0 = std::max(1, (batch + R - 1) / R);
         HIPCHK(d_ctl.alloc(L.words));
         HIPCHK(hipHostMalloc((void **)&h_ctl, L.words * sizeof(uint32_t)));
         ctx.ctl = d_ctl.p;
@@ -377,7 +391,7 @@ struct stcsp_engine {
         rc = alloc_edges(small_pools ? 8u : 1u << 15);
         if (rc != STCSP_OK) return rc;
         // outbox: [owner][region] x cand_cap records. Unsharded: emptied after every launch.
-        cand_cap = (uint32_t)(sharded ? std::max(4 * chunk_r, 4096) : chunk_r);
+        cand_cap = (uint32_t)(sharded ? std::max(4 * chunk_r, 4096) : 64);
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
@@ -526,6 +540,7 @@ struct stcsp_engine {
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
         memset(h_plan, 0, sizeof(Plan));
+        chunk_r = chunk_r0;
         h_plan->chunk_r = chunk_r;
         h_plan->chain_small = chain_small;
         h_plan->chain_big = chain_big;
@@ -667,7 +682,16 @@ struct stcsp_engine {
                 case PS_OUTBOX_FULL: return STCSP_OK;
                 case PS_NEED_ARENA: {
                     size_t need = (size_t)h_plan->arena_top + (size_t)R * (std::max(chain_small, chain_big) + 2) * chunk_r * ctx.NS;
-                    if ((rc = grow_arena(need)) || (rc = push_caps()) || (rc = replan())) return rc;
+                    // past the soft limit an automatic batch shrinks first (deeper, narrower search:
+                    // memory ~ depth x batch) and the arena only grows if that is not enough
+                    while (auto_batch && need > arena_soft_words && chunk_r > 2048) {
+                        chunk_r /= 2;
+                        h_plan->chunk_r = chunk_r;
+                        HIPCHK(hipMemcpyAsync(&d_plan.p->chunk_r, &h_plan->chunk_r, sizeof(int), hipMemcpyHostToDevice, stream));
+                        need = (size_t)h_plan->arena_top + (size_t)R * (std::max(chain_small, chain_big) + 2) * chunk_r * ctx.NS;
+                    }
+                    if (need > d_arena.n && (rc = grow_arena(need))) return rc;
+                    if ((rc = push_caps()) || (rc = replan())) return rc;
                     break;
                 }
                 case PS_NEED_EDGES:
@@ -699,7 +723,7 @@ struct stcsp_engine {
         if (opt.time_limit_s > 0 && elapsed() > opt.time_limit_s) return true;
         if (opt.max_search_nodes > 0) {
             // cheap upper bound without a device read: every launch expands at most chain*R*chunk_r nodes
-            if (levels * (long long)R * chunk_r * std::max(chain_small, chain_big) >= opt.max_search_nodes) {
+            if (levels * (long long)R * chunk_r0 * std::max(chain_small, chain_big) >= opt.max_search_nodes) {
                 std::vector<unsigned long long> st(kStatSlots * kStatWords);
                 if (hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                     long long nodes = 0;
