@@ -235,7 +235,9 @@ const char *stcsp_engine_last_error(const stcsp_engine *engine);
  *     outbox(peer) -> device ptr, count        fixed-size candidate records for `peer`
  *     <driver moves records between shards: RCCL all-to-all-v over xGMI>
  *     commit(device ptr, count)                lookup-or-insert each candidate's state, log its
- *                                              edge, open the successor node if the state is new
+ *                                              edge, open the successor node if the state is new.
+ *                                              Asynchronous: the records must stay valid until the
+ *                                              next expand_local() / finish() returns
  *     stop when every shard has no open node and no candidate
  *   export() per shard; stcsp_merge_shards() on the gathering rank.
  *

@@ -118,6 +118,7 @@ struct stcsp_engine {
     std::vector<unsigned long long> dbg_nodes;
     std::vector<long long> dbg_open;
     bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true>
+    bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
     std::vector<uint32_t *> pack_ptr;
     std::vector<int64_t> pack_count;
@@ -900,6 +901,7 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         rc = read_ctl();  // outbox cursors for outbox()
         if (rc != STCSP_OK) return rc;
+        host_view_fresh = true;
         if (left) *left = truncated ? 0 : (int64_t)h_plan->open_total;
         return STCSP_OK;
     }
@@ -947,11 +949,14 @@ struct stcsp_engine {
             HIPCHK(hipStreamSynchronize(stream));
             return STCSP_OK;
         }
-        // room for `count` more edges / states and for the segment of new nodes
-        int rc = read_ctl();
-        if (rc != STCSP_OK) return rc;
-        rc = read_plan();
-        if (rc != STCSP_OK) return rc;
+        // room for `count` more edges / states and for the segment of new nodes. The host copies of
+        // the cursors and the plan are those expand_local() just read (nothing ran in between).
+        int rc = STCSP_OK;
+        if (!host_view_fresh) {
+            if ((rc = read_ctl()) != STCSP_OK) return rc;
+            if ((rc = read_plan()) != STCSP_OK) return rc;
+        }
+        host_view_fresh = false;
         const long long per_region = (count + R - 1) / R + 1;
         uint32_t max_edges = 0;
         for (int r = 0; r < R; r++) max_edges = std::max(max_edges, edge_count[r]);
@@ -979,9 +984,10 @@ struct stcsp_engine {
         }
         hipLaunchKernelGGL(k_close_segment, dim3(1), dim3(64), 0, stream, ctx);
         HIPCHK(hipGetLastError());
-        rc = read_ctl();
-        if (rc != STCSP_OK) return rc;
-        return read_plan();
+        // not waited for: the next expand_local() (or finish()) synchronises and reads the cursors,
+        // which is also where an overflow reported by k_commit surfaces. `records` must stay valid
+        // until then (the driver keeps its receive buffer for the whole superstep).
+        return STCSP_OK;
     }
 
     // graphTraverse / adversarialTraverse / adversarialTraverse2 on the device (dev_postproc.hpp)
