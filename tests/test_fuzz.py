@@ -12,8 +12,8 @@ from conftest import finish
 from fuzz_models import random_model
 
 
-def solve_canonical(stcsp, cls, text, **opts):
-    m = stcsp.Model(text=text)
+def solve_canonical(stcsp, cls, text, prefix_k=2, **opts):
+    m = stcsp.Model(text=text, prefix_k=prefix_k)
     e = cls(m, **opts)
     r = e.solve()
     a, _ = finish(e, r)
@@ -53,6 +53,42 @@ def test_fuzz_engine_matches_reference_restatement(stcsp, RefOracle, block):
             assert (re_.n_states, re_.counters.search_nodes) == (r.n_states, r.counters.search_nodes), f"seed {seed}\n{text}"
         checked += 1
     assert checked >= 90
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_fuzz_frontier_model_other_windows(stcsp, RefOracle, FrontierModel, k):
+    """Look-ahead windows other than the reference's default (-k1: no look-ahead at all, -k3)."""
+    checked = 0
+    for seed in range(200):
+        text = random_model(seed)
+        _, r, a = solve_canonical(stcsp, RefOracle, text, prefix_k=k, time_limit_s=5)
+        if r.truncated:
+            continue
+        _, rf, af = solve_canonical(stcsp, FrontierModel, text, prefix_k=k)
+        assert af.canonical() == a.canonical(), f"k {k} seed {seed}\n{text}"
+        assert rf.counters.dominance == r.counters.dominance, f"k {k} seed {seed}\n{text}"
+        checked += 1
+    assert checked >= 180
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_fuzz_engine_other_windows(stcsp, RefOracle, k):
+    checked = 0
+    for seed in range(150):
+        text = random_model(seed)
+        _, r, a = solve_canonical(stcsp, RefOracle, text, prefix_k=k, time_limit_s=5)
+        if r.truncated:
+            continue
+        try:
+            _, re_, ae = solve_canonical(stcsp, stcsp.Engine, text, prefix_k=k)
+        except stcsp.StcspError as ex:
+            assert ex.code == -2, f"k {k} seed {seed}: {ex}\n{text}"
+            continue
+        assert ae.canonical() == a.canonical(), f"k {k} seed {seed}\n{text}"
+        assert re_.counters.dominance == r.counters.dominance, f"k {k} seed {seed}\n{text}"
+        checked += 1
+    assert checked >= 130
 
 
 @pytest.mark.gpu
