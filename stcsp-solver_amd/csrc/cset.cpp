@@ -580,6 +580,8 @@ int SetManager::compile(FlatProgram &out) {
         }
         sd.tag = s.tag;
         std::vector<ItemDesc> small_items, wave_items;
+        std::vector<uint32_t> nxt((size_t)N * K * 2, 0u);  // eager X == next Y partners per block word (SetDesc::next_off)
+        bool any_next = false;
         for (size_t ci = 0; ci < s.cons.size(); ci++) {
             HostCon &c = s.cons[ci];
             ConDesc cd{};
@@ -610,6 +612,28 @@ int SetManager::compile(FlatProgram &out) {
             const int con_abs = (int)out.cons.size();
             if (c.type == CT_NEXT) {
                 for (int p = 0; p + 1 < K; p++) {
+                    // an arc whose two words have no eager partner of that kind yet is kept consistent
+                    // by close_next() after every change of either word; only the others become items
+                    const int wx = p * N + c.x, wy = (p + 1) * N + c.y;
+                    int sh = lb[c.x] - lb[c.y];
+                    sh = sh > 32 ? 32 : (sh < -32 ? -32 : sh);
+                    auto side_free = [&](int w, uint32_t side) {  // no eager partner on that side of word w yet, and a free entry
+                        for (int k = 0; k < 2; k++) {
+                            const uint32_t e = nxt[(size_t)w * 2 + k];
+                            if (e && ((e >> 24) & 1u) == side) return false;
+                        }
+                        return nxt[(size_t)w * 2] == 0 || nxt[(size_t)w * 2 + 1] == 0;
+                    };
+                    if (side_free(wx, 0u) && side_free(wy, 1u)) {
+                        auto put = [&](int w, int partner, uint32_t side) {
+                            const size_t k = nxt[(size_t)w * 2] == 0 ? 0 : 1;
+                            nxt[(size_t)w * 2 + k] = (uint32_t)(partner + 1) | (uint32_t)(sh + 64) << 16 | side << 24;
+                        };
+                        put(wx, wy, 0u);
+                        put(wy, wx, 1u);
+                        any_next = true;
+                        continue;
+                    }
                     ItemDesc it{};
                     it.type = IT_NEXT;
                     it.point = p;
@@ -665,6 +689,11 @@ int SetManager::compile(FlatProgram &out) {
             out.cons.push_back(cd);
             if (c.type != CT_AT)  // AT constraints are never revised (solveralgorithm.cpp:658-662)
                 for (int v : c.scope) out.varcons[sd.varcons_off + (size_t)v * sd.cw + ci / 32] |= 1u << (ci % 32);
+        }
+        sd.next_off = -1;
+        if (any_next) {
+            sd.next_off = (int32_t)out.nextpart.size();
+            out.nextpart.insert(out.nextpart.end(), nxt.begin(), nxt.end());
         }
         // items: lane-revised ones first, then the wavefront-revised ones
         sd.item_begin = (int32_t)out.items.size();

@@ -46,7 +46,7 @@ struct FlatProgram {
     std::vector<uint32_t> varcons;
     std::vector<TransDesc> trans;
     std::vector<ItemDesc> items;
-    std::vector<uint32_t> itemrows, tables;
+    std::vector<uint32_t> itemrows, tables, nextpart;
     std::vector<int32_t> strides;
     int max_stack = 1;
     int max_cw = 1;

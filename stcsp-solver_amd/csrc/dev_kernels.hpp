@@ -426,10 +426,12 @@ __global__ void k_close_segment(Ctx c) {
 #ifndef STCSP_EXPAND_WAVES
 #define STCSP_EXPAND_WAVES 1
 #endif
-// Ctx is read through a pointer (scalar loads on demand): passing it by value kept ~130 SGPRs
+// Register budget: 4 wavefronts/SIMD for the 1- and 2-register blocks, 3 for the 4-register one (the
+// allocator lands a few registers above those limits otherwise and loses a whole wavefront per SIMD;
+// the handful of spills this forces sit in cold paths). Ctx is read through a pointer (scalar loads on demand): passing it by value kept ~130 SGPRs
 // live/spilled and cost a wavefront of occupancy per SIMD.
 template <int DR, bool L, bool CS>
-__global__ __launch_bounds__(256, STCSP_EXPAND_WAVES) void k_expand(const Ctx *__restrict__ cp) {
+__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (DR <= 2 ? 4 : 3))) void k_expand(const Ctx *__restrict__ cp) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end

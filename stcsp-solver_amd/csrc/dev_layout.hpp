@@ -62,7 +62,7 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
        ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
 
 struct ImgOff {
-    int sets, cons, scope, strides, items, sweep, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
+    int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
         arr_off, words;
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };

@@ -236,7 +236,7 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
 template <int DR, bool L>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
-                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc) {
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc, bool &pruned) {
     const unsigned long long t_rv0 = PHASE_NOW();
     (void)t_rv0;
     const int s = C.scope_len;
@@ -343,29 +343,46 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     unsigned long long iters = 0;
     int stage_a_left = highmask ? maxn : 1;
     bool stage_b = false;
-    // next block of tuples: stage A probes, then (with high variables) the all-zero odometer block,
-    // then the odometer in order. false = the product is exhausted.
-    auto next_block = [&]() -> bool {
+    for (;;) {
         if (stage_a_left > 0) {
             if (is_high) {
-                const int it = maxn - stage_a_left;
+                int it = maxn - stage_a_left;
                 curbit = select_kth_fast(D, it - n * small_div(it, n));
                 curval = vlb + curbit;
             }
             stage_a_left--;
-            return true;
-        }
-        if (!highmask) return false;  // no high variables: the lanes covered the whole product in one block
-        if (!stage_b) {
-            stage_b = true;
+        } else if (!stage_b) {
+            stage_b = true;  // first exhaustive tuple block: all high digits 0
             if (is_high) {
                 digit_h = 0;
                 curbit = __ffs((int)D) - 1;
                 curval = vlb + curbit;
             }
-            return true;
         }
-        bool carry = true;  // advance the odometer (wave-uniform carry chain over the high variables)
+        int res;
+        if (use_bitmap) {
+            int bit = lane_part + base_sum;
+            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+                const int j = __ffsll((long long)hm) - 1;
+                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
+            }
+            res = active ? (int)(((uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
+        } else {
+            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        }
+        ws.evals += nact;
+        const unsigned long long sm = __ballot(active && res != 0);
+        if (sm) {
+            any_sat = true;
+            if (pairlane && (M & sm)) hit = true;
+            if (is_high) hs |= 1u << curbit;
+        }
+        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
+        if (stage_a_left > 0) continue;
+        if (!highmask) break;  // no high variables: the lanes covered the whole product
+        if (!stage_b) continue;
+        // advance the odometer (wave-uniform carry chain over the high variables)
+        bool carry = true;
         for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
             const int j = __ffsll((long long)hm) - 1;
             int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
@@ -380,56 +397,11 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
                 curval = vlb + curbit;
             }
         }
-        return !carry;
-    };
-    // tuple-bitmap lookups are pipelined one block deep: the word of block i+1 is requested before
-    // block i's answer is used (the bitmaps of large models live in HBM/L2, ~2 k cycles away)
-    auto bitmap_index = [&]() -> int {
-        int bit = lane_part + base_sum;
-        for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
-            const int j = __ffsll((long long)hm) - 1;
-            bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
-        }
-        return bit;
-    };
-    next_block();  // the first block always exists
-    int bit_cur = 0;
-    uint32_t word_cur = 0;
-    if (use_bitmap) {
-        bit_cur = bitmap_index();
-        word_cur = active ? (uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit_cur >> 5)) : 0u;
-    }
-    for (;;) {
-        const int curbit_cur = curbit;  // the block whose answer is consumed in this trip
-        int res, bit_nxt = 0;
-        uint32_t word_nxt = 0;
-        bool more;
-        if (use_bitmap) {
-            more = next_block();
-            if (more) {
-                bit_nxt = bitmap_index();
-                word_nxt = active ? (uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit_nxt >> 5)) : 0u;
-            }
-            res = (int)((word_cur >> (bit_cur & 31)) & 1u);
-        } else {
-            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
-            more = next_block();
-        }
-        ws.evals += nact;
-        const unsigned long long sm = __ballot(active && res != 0);
-        if (sm) {
-            any_sat = true;
-            if (pairlane && (M & sm)) hit = true;
-            if (is_high) hs |= 1u << curbit_cur;
-        }
-        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
-        if (!more) break;  // product exhausted
+        if (carry) break;  // wrapped around: product exhausted
         if (++iters > (1ull << 22)) {
             if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
             return false;
         }
-        bit_cur = bit_nxt;
-        word_cur = word_nxt;
     }
     const unsigned long long t_rv2 = PHASE_NOW();
     (void)t_rv2;
@@ -451,6 +423,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         }
         if (newD == 0) return false;
         if (newD != Dj) {
+            pruned = true;
             const int vj = (int)rdlane((uint32_t)var, j);
             dom.set(p * c.N + vj, newD, lane);
             if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
@@ -533,6 +506,73 @@ __device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_ba
 // node like solverSolveRe does: failed / branch / leaf (or "miss": a leaf whose constraint-set
 // translation the host has not provided yet). Outputs stay in registers; the callers (the
 // round-based k_expand and the persistent k_persist) decide where children and leaves go.
+// OR the dirty rows of every block word in `cm` (bit l = word q*64 + l changed) into the lane-striped
+// dirty mask, four words per trip (independent reads).
+template <bool L>
+__device__ __forceinline__ void mark_dirty_rows(const Ctx &c, const Img<L> &P, const SetDesc &S, int q, unsigned long long cm, int lane,
+                                                uint32_t &dirtyw) {
+    while (cm) {
+        const int l0 = __ffsll((long long)cm) - 1;
+        cm &= cm - 1;
+        const int l1 = cm ? __ffsll((long long)cm) - 1 : l0;
+        cm &= cm - 1;
+        const int l2 = cm ? __ffsll((long long)cm) - 1 : l0;
+        cm &= cm - 1;
+        const int l3 = cm ? __ffsll((long long)cm) - 1 : l0;
+        cm &= cm - 1;
+        if (lane < S.iw) {
+            const int rows = c.o.itemrows + S.itemrows_off + lane;
+            const uint32_t r0 = (uint32_t)P.v(rows + (q * 64 + l0) * S.iw), r1 = (uint32_t)P.v(rows + (q * 64 + l1) * S.iw);
+            const uint32_t r2 = (uint32_t)P.v(rows + (q * 64 + l2) * S.iw), r3 = (uint32_t)P.v(rows + (q * 64 + l3) * S.iw);
+            dirtyw |= r0 | r1 | r2 | r3;
+        }
+    }
+}
+
+// Eager consistency of the X == next Y arcs (role of enforceNextConsistency, solveralgorithm.cpp:544-593):
+// every block word intersects itself with its partners' domains (SetDesc::next_off), repeated until
+// nothing changes (one pass for K = 2). Run after every change of the block, so that these arcs are
+// never work items and their prunings do not cost a sweep of their own. Returns false on a wipe-out.
+template <int DR, bool L>
+__device__ bool close_next(const Ctx &c, const Img<L> &P, const SetDesc &S, Dom<DR> &dom, int lane, int *ldom, uint32_t &dirtyw) {
+    const int base = c.o.nextpart + S.next_off;
+    // what one entry allows: the partner's domain shifted into this word's value numbering
+    auto allowed = [](uint32_t e, uint32_t partner) -> uint32_t {
+        if (!e) return 0xffffffffu;
+        const int sh = (int)((e >> 16) & 0xffu) - 64;
+        const bool up = ((e >> 24) & 1u) ? sh >= 0 : sh < 0;  // side 0 (X): Y >> sh; side 1 (Y): X << sh
+        const int a = sh >= 0 ? sh : -sh;
+        return a >= 32 ? 0u : (up ? partner << a : partner >> a);
+    };
+    for (int pass = 0; pass < 64; pass++) {
+        bool changed = false;
+#pragma unroll
+        for (int q = 0; q < DR; q++) {
+            const int idx = q * 64 + lane;
+            const bool in = idx < c.NK;
+            const uint32_t e0 = in ? (uint32_t)P.v(base + idx * 2) : 0u;
+            // gathers are executed by every lane (cross-lane reads need the source lanes active)
+            uint32_t nd = dom.r[q] & allowed(e0, dom.gather(e0 ? (int)(e0 & 0xffffu) - 1 : 0));
+            if (c.K > 2) {  // a word can sit on both sides of arcs only with more than two time points
+                const uint32_t e1 = in ? (uint32_t)P.v(base + idx * 2 + 1) : 0u;
+                if (__ballot(e1 != 0)) nd &= allowed(e1, dom.gather(e1 ? (int)(e1 & 0xffffu) - 1 : 0));
+            }
+            if (__ballot(in && nd == 0)) return false;
+            const unsigned long long cm = __ballot(nd != dom.r[q]);
+            if (cm) {
+                if (nd != dom.r[q]) ldom[idx] = (int)nd;  // keep the sweeps' LDS copy current
+                dom.r[q] = nd;
+                mark_dirty_rows<L>(c, P, S, q, cm, lane, dirtyw);
+                changed = true;
+            }
+        }
+        // K = 2: arcs only join a point-0 word with a point-1 word, one partner each -- both ends now
+        // hold the same (shifted) set, a second pass cannot change anything
+        if (!changed || c.K == 2) break;
+    }
+    return true;
+}
+
 template <int DR, bool L, bool CS>
 __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, Dom<DR> &dom,
                             const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
@@ -576,7 +616,16 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         if (idx < c.NK) ldom[idx] = (int)dom.r[q];
     }
     if (lane == 0) ldom[c.NK] = 0;  // rows examined by the sweeps of this node (statistics)
+    // the X == next Y arcs that are not items: the parent kept them consistent, the bisection (or the
+    // time shift of a fresh state) may have broken them
+    bool need_close = S.next_off >= 0 && seed != 0xffffu;
     while (consistent) {
+        if (need_close) {  // the only call site: after any change of the block, before anything else is revised
+            need_close = false;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            consistent = close_next<DR, L>(c, P, S, dom, lane, ldom, dirtyw);
+            if (!consistent) break;
+        }
         if (__ballot((dirtyw & smallmask) != 0)) {
             const unsigned long long t_sw = PHASE_NOW();
             // ---- lane-parallel sweep over the dirty small items
@@ -730,6 +779,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 break;
             }
             // read the intersection back; every changed word re-dirties the items that read it
+            bool swept_change = false;
 #pragma unroll
             for (int q = 0; q < DR; q++) {
                 int idx = q * 64 + lane;
@@ -737,23 +787,10 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 if (__ballot(idx < c.NK && nd == 0)) consistent = false;
                 unsigned long long cm = __ballot(nd != dom.r[q]);
                 dom.r[q] = nd;
-                while (cm) {  // four changed words per trip: their dirty rows are independent reads
-                    const int l0 = __ffsll((long long)cm) - 1;
-                    cm &= cm - 1;
-                    const int l1 = cm ? __ffsll((long long)cm) - 1 : l0;
-                    cm &= cm - 1;
-                    const int l2 = cm ? __ffsll((long long)cm) - 1 : l0;
-                    cm &= cm - 1;
-                    const int l3 = cm ? __ffsll((long long)cm) - 1 : l0;
-                    cm &= cm - 1;
-                    if (lane < S.iw) {
-                        const int rows = c.o.itemrows + S.itemrows_off + lane;
-                        const uint32_t r0 = (uint32_t)P.v(rows + (q * 64 + l0) * S.iw), r1 = (uint32_t)P.v(rows + (q * 64 + l1) * S.iw);
-                        const uint32_t r2 = (uint32_t)P.v(rows + (q * 64 + l2) * S.iw), r3 = (uint32_t)P.v(rows + (q * 64 + l3) * S.iw);
-                        dirtyw |= r0 | r1 | r2 | r3;
-                    }
-                }
+                mark_dirty_rows<L>(c, P, S, q, cm, lane, dirtyw);
+                swept_change = swept_change || cm != 0;
             }
+            need_close = swept_change && S.next_off >= 0;
             if (++guard > (1u << 20)) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
                 consistent = false;
@@ -773,7 +810,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         const int ipoint = P.uc(ibase + 1), icon = P.uc(ibase + 2);
         ConDesc C;
         load_con<L>(c, P, icon, C);
-        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc);
+        bool pruned = false;
+        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc, pruned);
+        need_close = pruned && S.next_off >= 0;
         ws.cyc_wave += PHASE_NOW() - t_wv;
         if (++guard > (1u << 20)) {
             if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);

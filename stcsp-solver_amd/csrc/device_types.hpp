@@ -123,8 +123,13 @@ struct SetDesc {          // one constraint set (entry of Solver::seenConstraint
     int32_t nsmall;       // items [0, nsmall) are lane-revised
     int32_t iw;           // dirty-mask words = (nitems + 31) / 32
     int32_t itemrows_off; // into itemrows[]: [N*K][iw] rows: items that read block word (p,v)
-    int32_t pad0;
+    int32_t next_off;     // into nextpart[]: [N*K][2] partner entries of the X == next Y arcs that are kept
+                          // consistent eagerly (close_next) instead of being items; -1: none in this set
 };
+// nextpart[word] = two entries; entry: 0 = none, else (partner block word + 1) | (lbX - lbY + 64) << 16 |
+// side << 24 (shift clamped to [-32, 32]; side 0: this word is X[p] and the partner Y[p+1], side 1: this
+// word is Y[p+1] and the partner X[p]). Entry 0 is used first; entry 1 only when the word is on both sides
+// of arcs (possible for K > 2 only).
 
 struct TransDesc {
     int32_t vals_off;     // into transvals[]: nfirst values

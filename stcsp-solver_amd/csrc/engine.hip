@@ -226,6 +226,7 @@ struct stcsp_engine {
             for (size_t i = 0; i < prog.items.size(); i++) pack_sweep_item(prog.items[i], &sweep[i * 4]);
             o.sweep = put(sweep.data(), sweep.size() * 4);
         }
+        o.nextpart = put(prog.nextpart.data(), prog.nextpart.size() * 4);
         o.var_lb = put(mgr.lb.data(), mgr.lb.size() * 4);
         o.var_init = put(init.data(), init.size() * 4);
         o.sig_vars = put(mgr.sig_vars.data(), mgr.sig_vars.size() * 4);
