@@ -618,7 +618,23 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     if (lane == 0) ldom[c.NK] = 0;  // rows examined by the sweeps of this node (statistics)
     // the X == next Y arcs that are not items: the parent kept them consistent, the bisection (or the
     // time shift of a fresh state) may have broken them
-    bool need_close = S.next_off >= 0 && seed != 0xffffu;
+    // pm[q]: block words (bit l = word q*64 + l) that have an eager partner; a closure is only due
+    // when such a word changed (scalar tests from here on)
+    unsigned long long pm[DR];
+    bool need_close = false;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        const int idx = q * 64 + lane;
+        pm[q] = S.next_off >= 0 ? __ballot(idx < c.NK && P.v(c.o.nextpart + S.next_off + idx * 2) != 0) : 0ull;
+    }
+    if (seed == 0) {
+        need_close = S.next_off >= 0;  // fresh state: the time shift may have broken any arc
+    } else if (seed != 0xffffu) {
+        const int w = (int)seed - 1;  // the parent bisected time-0 word w and was at its fixpoint otherwise
+#pragma unroll
+        for (int q = 0; q < DR; q++)
+            if ((w >> 6) == q) need_close = (pm[q] >> (w & 63)) & 1ull;
+    }
     while (consistent) {
         if (need_close) {  // the only call site: after any change of the block, before anything else is revised
             need_close = false;
@@ -788,9 +804,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 unsigned long long cm = __ballot(nd != dom.r[q]);
                 dom.r[q] = nd;
                 mark_dirty_rows<L>(c, P, S, q, cm, lane, dirtyw);
-                swept_change = swept_change || cm != 0;
+                swept_change = swept_change || (cm & pm[q]) != 0;
             }
-            need_close = swept_change && S.next_off >= 0;
+            need_close = swept_change;  // a word with an eager partner changed
             if (++guard > (1u << 20)) {
                 if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
                 consistent = false;
