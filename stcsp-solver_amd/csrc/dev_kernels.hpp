@@ -167,16 +167,18 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
 
 __device__ __forceinline__ uint32_t ald(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Reductions of the round bookkeeping (non-negative counts, sums below 2^31): DPP scans as in
+// wave_scan_add, the result is taken from lane 63. All 64 lanes are active at every call.
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ long long wave_sum64(long long v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ long long wave_sum64(long long v) { return (long long)wave_sum((int)v); }
 
 // The round bookkeeping below is executed by ONE wavefront (lane r looks after cursor region r),
 // so that its global-memory reads go out in parallel: a handful of round trips per round.

@@ -102,7 +102,7 @@ struct Dom {
 #endif
 struct WaveStats {
     unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
-    unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0;
+    unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0, cyc_close = 0;
     unsigned long long evals = 0;   // wave-uniform: rows looked at by all lanes (sweeps) + tuples of wavefront revisions
 };
 
@@ -204,11 +204,20 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_val
     }
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// Inclusive prefix sum over the 64 lanes with DPP moves (row shifts inside each row of 16, then the two
+// row broadcasts): six VALU instructions, no LDS crossbar latency (a __shfl_xor butterfly is six
+// dependent ds_bpermute round trips, ~800 cycles). All 64 lanes must be active. Lane 63 ends up with
+// the total.
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v), 63); }
 
 // position of the k-th (0-based) set bit of m, branch-free (k < popcount(m))
 __device__ __forceinline__ int select_kth_fast(uint32_t m, int k) {
@@ -638,8 +647,10 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     while (consistent) {
         if (need_close) {  // the only call site: after any change of the block, before anything else is revised
             need_close = false;
+            const unsigned long long t_cl = PHASE_NOW();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             consistent = close_next<DR, L>(c, P, S, dom, lane, ldom, dirtyw);
+            ws.cyc_close += PHASE_NOW() - t_cl;
             if (!consistent) break;
         }
         if (__ballot((dirtyw & smallmask) != 0)) {
@@ -660,12 +671,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
             if (compact) {
                 dsm = lane < S.iw ? (dirtyw & smallmask) : 0u;
                 const int cnt = __popc(dsm);
-                int incl = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += up;
-                }
+                const int incl = wave_scan_add(cnt);
                 excl = incl - cnt;
                 total_dirty = (int)rdlane((uint32_t)incl, 63);
             }
@@ -850,6 +856,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_CYC_RV_SETUP, ws.cyc_rv_setup);
         add_stats(c, gw, ST_CYC_RV_LOOP, ws.cyc_rv_loop);
         add_stats(c, gw, ST_CYC_RV_WB, ws.cyc_rv_wb);
+        add_stats(c, gw, ST_CYC_CLOSE, ws.cyc_close);
 #endif
     }
     if (!consistent) {
@@ -877,6 +884,8 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         return OC_BRANCH;
     }
 
+    const unsigned long long t_leaf = PHASE_NOW();
+    (void)t_leaf;
     // ---- leaf: every variable has a single time-0 value (solveralgorithm.cpp:739-910)
     // (1) next constraint set: per-leaf translation (:755-805) via the transition table
     int next_set = set;
@@ -957,6 +966,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         lo.nblk[q] = nb;
     }
     if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+#ifdef STCSP_PHASES
+    if (lane == 0) add_stats(c, gw, ST_CYC_LEAF, PHASE_NOW() - t_leaf);
+#endif
     return OC_LEAF;
 }
 

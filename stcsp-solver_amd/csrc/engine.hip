@@ -860,6 +860,9 @@ struct stcsp_engine {
             fprintf(stderr, "[phases] per wavefront revision (completed ones): setup %.0f, enumeration %.0f, write-back %.0f cycles; %.2f revisions per node\n",
                     (double)tot[ST_CYC_RV_SETUP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_LOOP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_WB] / tot[ST_WAVEREVS],
                     (double)tot[ST_WAVEREVS] / tot[ST_NODES]);
+        if (tot[ST_NODES])
+            fprintf(stderr, "[phases] cycles/node: closures of the next arcs %.0f, leaf part of process_node (transition, signature, hash, time shift) %.0f\n",
+                    (double)tot[ST_CYC_CLOSE] / tot[ST_NODES], (double)tot[ST_CYC_LEAF] / tot[ST_NODES]);
         if (tot[ST_BLOCKS] && tot[ST_ROUNDS_FINAL])
             fprintf(stderr, "[phases] per working workgroup: image staging %.0f cycles, whole %.0f cycles (%llu workgroup runs); finalize_round %.0f cycles x %llu rounds\n",
                     (double)tot[ST_CYC_STAGE] / tot[ST_BLOCKS], (double)tot[ST_CYC_BLOCK] / tot[ST_BLOCKS], (unsigned long long)tot[ST_BLOCKS],
