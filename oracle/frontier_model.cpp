@@ -247,9 +247,7 @@ struct Model {
     }
 
     unsigned long long key_hash(const uint32_t *kw) const {
-        unsigned long long h = kHashSeed;
-        for (int j = 0; j < KL; j++) h = mix64(h, kw[j]);
-        return mix_final(h);
+        return stcsp::key_hash(kw, KL);
     }
 
     // expand one node: propagate, classify, emit children / a candidate

@@ -990,9 +990,7 @@ __global__ void k_pack(const uint32_t *cand_base, uint32_t cand_cap, int CS, con
 __global__ void k_rehash(Ctx c, uint32_t n_states) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
-    unsigned long long h = kHashSeed;
-    for (int j = 0; j < c.KL; j++) h = mix64(h, c.state_keys[(size_t)i * c.KL + j]);
-    h = mix_final(h);
+    const unsigned long long h = key_hash(c.state_keys + (size_t)i * c.KL, c.KL);
     const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
     uint32_t pos = (uint32_t)h & c.slot_mask;
     const unsigned long long want = ((unsigned long long)htag << 32) | i;

@@ -218,6 +218,18 @@ __device__ __forceinline__ int wave_scan_add(int v) {
     return v;
 }
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v), 63); }
+__device__ __forceinline__ uint32_t wave_xor32(uint32_t v) {
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_xor64(unsigned long long v) {
+    return (unsigned long long)wave_xor32((uint32_t)(v >> 32)) << 32 | wave_xor32((uint32_t)v);
+}
 
 // position of the k-th (0-based) set bit of m, branch-free (k < popcount(m))
 __device__ __forceinline__ int select_kth_fast(uint32_t m, int k) {
@@ -942,9 +954,12 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         if (lane == 0) kw = next_tag;
     }
     // (3) owner shard = hash(key) % world
-    unsigned long long h = kHashSeed;
-    for (int j = 0; j < c.KL; j++) h = mix64(h, rdlane(kw, j));
-    h = mix_final(h);
+    // lane j hashes key word j, the terms are XORed across the wavefront (key_hash, device_types.hpp)
+    unsigned long long h;
+    {
+        const unsigned long long t = lane < c.KL ? key_term(lane, kw) : 0ull;
+        h = mix_final(kHashSeed ^ wave_xor64(t));
+    }
     lo.kw = kw;
     lo.h = h;
     lo.next_set = next_set;

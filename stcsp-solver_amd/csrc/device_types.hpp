@@ -142,13 +142,16 @@ struct TransDesc {
 #define STCSP_HD inline
 #endif
 
-// hash of a state key (constraint-set tag, signature words): table slot, slot tag and, in
-// sharded runs, the owner shard = (h >> 40) % world.
-STCSP_HD unsigned long long mix64(unsigned long long h, uint32_t w) {
-    h ^= w;
-    h *= 0xBF58476D1CE4E5B9ull;
-    h ^= h >> 29;
-    return h;
+// Hash of a state key (constraint-set tag, signature words): table slot, slot tag and, in sharded
+// runs, the owner shard = (h >> 40) % world. Every word is mixed on its own (position-salted) and the
+// terms are XORed, so that a wavefront can hash a key with one lane per word and a cross-lane XOR
+// instead of a serial chain of 64-bit multiplies (dev_propagate.hpp) -- every implementation (device,
+// k_rehash, host root insertion, oracle/frontier_model.cpp) goes through these two functions.
+STCSP_HD unsigned long long key_term(int j, uint32_t w) {
+    unsigned long long t = ((unsigned long long)(uint32_t)(j + 1) << 32 | w) * 0xBF58476D1CE4E5B9ull;
+    t ^= t >> 29;
+    t *= 0x94D049BB133111EBull;
+    return t ^ (t >> 31);
 }
 STCSP_HD unsigned long long mix_final(unsigned long long h) {
     h *= 0x94D049BB133111EBull;
@@ -156,6 +159,11 @@ STCSP_HD unsigned long long mix_final(unsigned long long h) {
     return h;
 }
 constexpr unsigned long long kHashSeed = 0x9E3779B97F4A7C15ull;
+STCSP_HD unsigned long long key_hash(const uint32_t *key, int kl) {
+    unsigned long long h = kHashSeed;
+    for (int j = 0; j < kl; j++) h ^= key_term(j, key[j]);
+    return mix_final(h);
+}
 
 // record strides in words (all multiples of 4)
 STCSP_HD int node_stride(int N, int K) { return (4 + N * K + 3) & ~3; }

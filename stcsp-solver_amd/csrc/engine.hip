@@ -555,9 +555,7 @@ struct stcsp_engine {
             // (tag 0); otherwise a reserved tag keeps it apart from a state with an all-zero signature.
             std::vector<uint32_t> key(ctx.KL, 0u);
             key[0] = ctx.sig_len == 0 ? 0u : kRootTag;
-            unsigned long long h = kHashSeed;
-            for (int j = 0; j < ctx.KL; j++) h = mix64(h, key[j]);
-            h = mix_final(h);
+            const unsigned long long h = key_hash(key.data(), ctx.KL);
             uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
             unsigned long long slot = ((unsigned long long)htag << 32) | 0u;
             HIPCHK(hipMemcpyAsync(d_state_keys.p, key.data(), ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
