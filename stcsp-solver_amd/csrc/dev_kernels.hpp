@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 1 + 63) & ~63);
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     const int total_waves = gridDim.x * 4;
     const unsigned long long t_k1 = PHASE_NOW();
     (void)t_k1;
+    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;  // this wavefront's counters (process_node: lstat_add)
+    if (lane < kLdsStatWords) lstat[lane] = 0;
     for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS>(c, a, P, gw, lane, lds_vals, lds_stk);
+    flush_lds_stats(c, lstat, blockIdx.x * 4 + wib, lane);
     __syncthreads();
 #ifdef STCSP_PHASES
     if (threadIdx.x == 0) {
@@ -611,11 +614,13 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + 1 + 63) & ~63);
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
     const int wid = blockIdx.x * 4 + wib;
+    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;  // this wavefront's counters (process_node: lstat_add)
+    if (lane < kLdsStatWords) lstat[lane] = 0;
     uint32_t *mystack = c.pstack + (size_t)wid * c.pstk_cap * c.NS;
     const CtlLayout L_(c.world);
     uint32_t *misc = c.ctl + L_.misc0;
@@ -792,6 +797,7 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
         }
     }
     if (counted && lane == 0) atomicSub(&c.pq[PQ_PENDING], 1u);
+    flush_lds_stats(c, lstat, wid, lane);
     if (lane == 0) {
         dbg_idle += __builtin_amdgcn_s_memtime() - dbg_t;
         add_stats(c, wid, ST_QPUSH, dbg_push);

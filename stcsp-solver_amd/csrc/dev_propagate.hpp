@@ -478,6 +478,20 @@ __device__ __forceinline__ void load_con(const Ctx &c, const Img<L> &P, int idx,
 __device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
     if (v) atomicAdd(&c.stats[(gw % kStatSlots) * kStatWords + which], v);
 }
+// The per-node work counters (ST_NODES .. ST_SKIPPED) are summed in LDS by lane 0 and reach the global
+// statistics once per wavefront and launch: seven global atomics per node on 64 hot lines would sit in
+// vmcnt in front of the next node's loads.
+__device__ __forceinline__ void lstat_add(int *lstat, int which, unsigned v) {
+    if (v) atomicAdd((unsigned *)&lstat[1 + which], v);
+}
+__device__ __forceinline__ void flush_lds_stats(const Ctx &c, int *lstat, int slot, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane <= ST_SKIPPED) {
+        const unsigned v = (unsigned)lstat[1 + lane];
+        if (v) atomicAdd(&c.stats[(slot % kStatSlots) * kStatWords + lane], (unsigned long long)v);
+        lstat[1 + lane] = 0;
+    }
+}
 
 template <int DR>
 __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
@@ -856,12 +870,13 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         ws.evals += (unsigned)ldom[c.NK];
-        add_stats(c, gw, ST_NODES, 1);
-        add_stats(c, gw, ST_REVS, ws.revs);
-        add_stats(c, gw, ST_EVALS, ws.evals);
-        add_stats(c, gw, ST_WAVEREVS, ws.wave_revs);
-        add_stats(c, gw, ST_SWEEPS, ws.sweeps);
-        add_stats(c, gw, ST_SKIPPED, ws.skipped);
+        int *lstat = ldom + c.NK;
+        lstat_add(lstat, ST_NODES, 1);
+        lstat_add(lstat, ST_REVS, ws.revs);
+        lstat_add(lstat, ST_EVALS, (unsigned)ws.evals);
+        lstat_add(lstat, ST_WAVEREVS, ws.wave_revs);
+        lstat_add(lstat, ST_SWEEPS, ws.sweeps);
+        lstat_add(lstat, ST_SKIPPED, ws.skipped);
 #ifdef STCSP_PHASES
         add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
         add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
@@ -872,7 +887,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
 #endif
     }
     if (!consistent) {
-        if (lane == 0) add_stats(c, gw, ST_FAILS, 1);
+        if (lane == 0) lstat_add(ldom + c.NK, ST_FAILS, 1);
         return OC_FAIL;
     }
 
@@ -928,7 +943,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 }
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
-            if (lane == 0) add_stats(c, gw, ST_REQUEUE, 1);
+            if (lane == 0) lstat_add(ldom + c.NK, ST_REQUEUE, 1);
             return OC_MISS;
         }
     }
@@ -980,7 +995,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         }
         lo.nblk[q] = nb;
     }
-    if (lane == 0) add_stats(c, gw, ST_LEAVES, 1);
+    if (lane == 0) lstat_add(ldom + c.NK, ST_LEAVES, 1);
 #ifdef STCSP_PHASES
     if (lane == 0) add_stats(c, gw, ST_CYC_LEAF, PHASE_NOW() - t_leaf);
 #endif

@@ -257,7 +257,7 @@ struct stcsp_engine {
         compact_sweeps = false;
         for (const SetDesc &sd : prog.sets) compact_sweeps = compact_sweeps || sd.nsmall > kCompactSweepItems;
         ctx.stack_slots = prog.max_stack + 2;
-        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + 1 + 63) & ~63)) * sizeof(int);
+        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + kLdsStatWords + 63) & ~63)) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
