@@ -287,9 +287,18 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         const int nj = (int)rdlane((uint32_t)n, j);
         if (nlow < kMaxLowVars && P * nj <= 64) {
             const uint32_t Dj = rdlane(D, j);
-            const int q = small_div(lane, P);
-            const int digit = q - nj * small_div(q, nj);
-            const int bitpos = select_kth_fast(Dj, digit);
+            // digit of low variable j in this lane's tuple, and the value bit it stands for. P, nj and
+            // Dj are wave-uniform: powers of two divide by shifting, small domains (the common case:
+            // 0/1 variables) pick the digit-th set bit with two VALU operations per value
+            const int q = (P & (P - 1)) == 0 ? (lane >> (__ffs(P) - 1)) : small_div(lane, P);
+            const int digit = (nj & (nj - 1)) == 0 ? (q & (nj - 1)) : q - nj * small_div(q, nj);
+            int bitpos = 0;
+            if (nj <= 8) {
+                int k = 0;
+                for (uint32_t m = Dj; m; m &= m - 1, k++) bitpos = digit == k ? __ffs((int)m) - 1 : bitpos;
+            } else {
+                bitpos = select_kth_fast(Dj, digit);
+            }
             lds_vals[nlow * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
             if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
             if (lane == j) {
