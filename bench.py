@@ -84,6 +84,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # a fresh checkout has no built libraries: rank 0 compiles them once, the others wait
+    if rank == 0 and (not (st.CSRC / "libstcsp_hip.so").exists() or not (REPO / "oracle" / "libstcsp_oracle.so").exists()):
+        import __graft_entry__
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
 
     model = st.Model.from_name(args.workload)
     flags = st.F_NO_EXPORT | st.F_PROFILE

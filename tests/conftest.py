@@ -30,6 +30,7 @@ def _ensure(path: Path, make_dir: Path, target: str):
 @pytest.fixture(scope="session")
 def stcsp():
     _ensure(st.CSRC / "libstcsp_host.so", st.CSRC, "libstcsp_host.so")
+    _ensure(st.CSRC / "libstcsp_hip.so", st.CSRC, "libstcsp_hip.so")  # hipcc cross-compiles without a GPU
     return st
 
 
