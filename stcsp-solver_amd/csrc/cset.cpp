@@ -466,6 +466,7 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
     is_small = false;
     cd.bitmap_off = -1;
     cd.stride_off = 0;
+    cd.n_forbidden = -1;
     const int s = (int)c.scope.size();
     if (c.type != CT_POINT || s == 0) return;
     std::vector<int> size(s);
@@ -539,12 +540,15 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
         }
         if (holds()) bm[t >> 5] |= 1u << (t & 31);
     }
+    long long allowed = 0;
+    for (size_t w = 0; w < (size_t)((product + 31) / 32); w++) allowed += __builtin_popcount(bm[w]);
+    cd.n_forbidden = product - allowed <= kFewForbidden ? (int32_t)(product - allowed) : -1;
 }
 
 int SetManager::compile(FlatProgram &out) {
     out = FlatProgram();
     struct TableCacheEntry {
-        int32_t bitmap_off, stride_off;
+        int32_t bitmap_off, stride_off, n_forbidden;
         bool is_small;
         ItemDesc small;
     };
@@ -585,6 +589,7 @@ int SetManager::compile(FlatProgram &out) {
         for (size_t ci = 0; ci < s.cons.size(); ci++) {
             HostCon &c = s.cons[ci];
             ConDesc cd{};
+            cd.n_forbidden = -1;
             cd.type = c.type;
             cd.npoints = c.has_first ? 1 : K;
             cd.scope_off = (int32_t)out.scope.size();
@@ -663,11 +668,12 @@ int SetManager::compile(FlatProgram &out) {
                 if (hit != table_cache.end()) {
                     cd.bitmap_off = hit->second.bitmap_off;
                     cd.stride_off = hit->second.stride_off;
+                    cd.n_forbidden = hit->second.n_forbidden;
                     is_small = hit->second.is_small;
                     if (is_small) proto.push_back(hit->second.small);
                 } else {
                     build_tables(c, cd, out, proto, is_small);
-                    TableCacheEntry e{cd.bitmap_off, cd.stride_off, is_small, is_small ? proto[0] : ItemDesc{}};
+                    TableCacheEntry e{cd.bitmap_off, cd.stride_off, cd.n_forbidden, is_small, is_small ? proto[0] : ItemDesc{}};
                     table_cache.emplace(key, e);
                 }
                 for (int p = 0; p < cd.npoints; p++) {

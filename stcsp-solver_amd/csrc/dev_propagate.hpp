@@ -268,6 +268,23 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     if (lane >= s) D = 0;
     const int n = lane < s ? __popc(D) : 1;
     if (__ballot(lane < s && n == 0)) return false;
+    // Constraints with few violating tuples in all (wide disjunctions / implications such as
+    // succ >= (seen0 and ... and seen13): one violating tuple out of 2^15): a value loses its support
+    // only when the whole product of the OTHER domains is forbidden, so unless
+    // prod(all domains) / (largest domain) <= n_forbidden this revision cannot prune anything.
+    if (C.n_forbidden >= 0) {
+        unsigned long long prod = 1;
+        int largest = 1;
+        for (unsigned long long m = __ballot(lane < s && n > 1); m && prod <= (unsigned long long)kFewForbidden * 32u; m &= m - 1) {
+            const int nj = (int)rdlane((uint32_t)n, __ffsll((long long)m) - 1);
+            prod *= (unsigned long long)nj;
+            if (nj > largest) largest = nj;
+        }
+        if (prod > (unsigned long long)C.n_forbidden * (unsigned long long)largest) {
+            if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+            return true;
+        }
+    }
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
     const bool use_bitmap = C.bitmap_off >= 0;
     const int mystride = (use_bitmap && lane < s) ? G.vc(c.o.strides + C.stride_off + lane) : 0;

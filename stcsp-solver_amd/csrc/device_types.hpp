@@ -70,7 +70,13 @@ struct ConDesc {          // one constraint of one constraint set
     int32_t bitmap_off;   // >= 0: into tables[], satisfying-tuple bitmap over the full initial
                           //       product (bit index = sum_j bitpos_j * stride_j); -1: interpret code
     int32_t stride_off;   // into strides[] (parallel to the scope) when bitmap_off >= 0
+    int32_t n_forbidden;  // bitmap constraints: number of violating tuples of the full product when that is
+                          // at most kFewForbidden, else -1. A value can only lose its support when the
+                          // product of the OTHER domains fits inside the forbidden set, so a revision with
+                          // (product of all domains) / (largest domain) > n_forbidden cannot prune and is skipped.
+    int32_t pad1;
 };
+constexpr int kFewForbidden = 64;
 
 // A propagation work item = one constraint at one time point. Items are what the dirty mask
 // tracks; items [0, nsmall) of a set are "small" (one lane revises one item), the rest are
