@@ -285,9 +285,44 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             return true;
         }
     }
-    const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
     const bool use_bitmap = C.bitmap_off >= 0;
     const int mystride = (use_bitmap && lane < s) ? G.vc(c.o.strides + C.stride_off + lane) : 0;
+    // Fast path (tuple-bitmap constraints): at most ONE scope variable is not yet fixed -- the usual
+    // situation deep in the tree. No tuple enumeration to set up: lane v looks value v of that variable
+    // up (one block of <= 32 tuples), or the single tuple is checked when everything is fixed.
+    {
+        const unsigned long long open_vars = __ballot(lane < s && n > 1);
+        if (use_bitmap && (open_vars & (open_vars - 1)) == 0) {
+            const int fixed_part = wave_sum((lane < s && n == 1) ? (__ffs((int)D) - 1) * mystride : 0);
+            const int tab = c.o.tables + C.bitmap_off;
+            ws.revs++;
+            ws.wave_revs++;
+            if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+            if (!open_vars) {
+                ws.evals += 1;
+                return (((uint32_t)G.vc(tab + (fixed_part >> 5)) >> (fixed_part & 31)) & 1u) != 0;
+            }
+            const int j = __ffsll((long long)open_vars) - 1;
+            const uint32_t Dj = rdlane(D, j);
+            const int strj = (int)rdlane((uint32_t)mystride, j);
+            const bool has = lane < 32 && ((Dj >> lane) & 1u);
+            const int bit = fixed_part + lane * strj;
+            const bool sat = has && ((((uint32_t)G.vc(tab + (bit >> 5))) >> (bit & 31)) & 1u);
+            const uint32_t newD = (uint32_t)__ballot(sat);
+            ws.evals += (unsigned)__popc(Dj);
+            if (newD == 0) return false;
+            if (newD != Dj) {
+                pruned = true;
+                const int w = p * c.N + (int)rdlane((uint32_t)var, j);
+                dom.set(w, newD, lane);
+                if (lane == 0) ldom[w] = (int)newD;  // keep the sweep's LDS copy of the block current
+                if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + w * S.iw + lane);
+                if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));  // a revision is a fixpoint for its own constraint
+            }
+            return true;
+        }
+    }
+    const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
 
     // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
     // multiply to <= 64 are enumerated ACROSS LANES (lane index = mixed-radix tuple index), the rest
