@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stepped", action="store_true",
+                    help="N=1 only: run the sharded pipeline (size-1 RCCL group, STCSP_F_STEPPED) -- the N>1 code path on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -81,8 +83,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    stepped = world > 1 or args.stepped
+    if stepped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # a fresh checkout has no built libraries: rank 0 compiles them once, the others wait
     if rank == 0 and (not (st.CSRC / "libstcsp_hip.so").exists() or not (REPO / "oracle" / "libstcsp_oracle.so").exists()):
@@ -92,11 +96,11 @@ def main():
         dist.barrier()
 
     model = st.Model.from_name(args.workload)
-    flags = st.F_NO_EXPORT | st.F_PROFILE
+    flags = st.F_NO_EXPORT | st.F_PROFILE | (st.F_STEPPED if args.stepped and world == 1 else 0)
     eng = st.Engine(model, device=local_rank, rank=rank, world=world, flags=flags, batch_nodes=args.batch)
 
     def one_step():
-        if world == 1:
+        if not stepped:
             return eng.solve().counters  # the engine reads its counters once, at the end of the solve
         from importlib import import_module
         sh = import_module("stcsp-solver_amd.sharded")
@@ -104,7 +108,7 @@ def main():
         return eng.counters()
 
     def barrier():
-        if world > 1:
+        if stepped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -128,7 +132,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     levels = c.levels
-    if world > 1:
+    if stepped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -139,7 +143,7 @@ def main():
     # automaton export cost (PCIe D2H + ok-fixpoint), outside the timed region
     export_ms = None
     check = {}
-    if world == 1:
+    if not stepped:
         t1 = time.perf_counter()
         res = eng.export()
         export_first_ms = (time.perf_counter() - t1) * 1e3  # includes pinning the result buffers
@@ -151,10 +155,23 @@ def main():
         a = eng.automaton(res).traverse().renumber()
         check = {"states": a.n_live_states, "edges": a.n_live_edges, "canonical_sha256": a.canonical_sha256()}
 
+    if stepped:
+        # parity of the sharded run (outside the timed region): gather the shards, merge, canonical hash
+        try:
+            from importlib import import_module
+            sh = import_module("stcsp-solver_amd.sharded")
+            merged = sh.gather_and_merge(st, eng, rank, world)
+            if rank == 0:
+                _, mres = merged
+                a = st.Automaton(model, mres).traverse().renumber()
+                check = {"states": a.n_live_states, "edges": a.n_live_edges, "canonical_sha256": a.canonical_sha256()}
+        except Exception as ex:  # the throughput line must survive a failure of the check
+            check = {"error": f"{type(ex).__name__}: {ex}"}
+
     if rank == 0:
         p = model.problem.contents
         N, K = p.n_vars, p.prefix_k
-        S = res.sig_len if world == 1 else 0
+        S = res.sig_len if not stepped else model.n_vars  # sharded runs: upper bound for the per-leaf key bytes
         # B_node = 2*N*K*W*4 (read the parent block, write the child block)
         # + per leaf: key probe + key store + edge record
         b_node = 2 * N * K * 1 * 4
@@ -168,7 +185,7 @@ def main():
         # over every k_expand dispatch of one solve (gfx950-corrected); per launch = / launches per solve
         traffic = None
         tf = REPO / "profiles" / "r01_chain_p14_traffic.json"
-        if args.workload == WORKLOAD and world == 1 and tf.exists() and k_launches:
+        if args.workload == WORKLOAD and not stepped and tf.exists() and k_launches:
             traffic = json.loads(tf.read_text())["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
         out = {
             "metric": "search-tree nodes/sec on partialorder_14.csp",
@@ -189,20 +206,20 @@ def main():
                        "launch_rounds_per_step": int(levels),
                        "per_node": {"item_revisions": revs / max(nodes, 1), "tuple_evaluations": evals / max(nodes, 1),
                                     "wavefront_revisions": wrevs / max(nodes, 1), "sweeps": sweeps / max(nodes, 1)},
-                       "sharding": "none" if world == 1 else f"state-owner x{world}"},
+                       "sharding": "none" if not stepped else f"state-owner x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_expand",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,
                          "launches": k_launches, "bytes_per_node": b_node, "bytes_per_leaf": b_leaf,
                          "kernel_time_share": k_time / elapsed if elapsed > 0 else None},
             "export_ms": export_ms,
-            "export_first_ms": export_first_ms if world == 1 else None,
+            "export_first_ms": export_first_ms if not stepped else None,
             "parity": check,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.stepped:
             out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if stepped:
         dist.destroy_process_group()
 
 
