@@ -122,7 +122,10 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
             return;
         }
         // leaf
-        if (c.sharded) {  // candidate record for the owner: header, signature, edge label, block
+        // sharded runs: a leaf whose successor state belongs to another shard becomes a candidate
+        // record for its owner (header, signature, edge label, block); one that belongs to this
+        // shard is committed right here like in an unsharded run
+        if (c.sharded && lo.owner != c.rank) {
             uint32_t pos = 0;
             if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
             pos = rflu(pos);
@@ -146,7 +149,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
             }
             return;
         }
-        // unsharded: commit right here, the leaf's data never leaves the registers
+        // commit right here, the leaf's data never leaves the registers
         CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, gw);
         if (!(co.ok && co.is_new)) return;
         if (last) {
