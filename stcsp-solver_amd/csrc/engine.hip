@@ -373,6 +373,7 @@ struct stcsp_engine {
             size_t free_b = 0, total_b = 0;
             arena_soft_words = ((size_t)8 << 30) / 4;  // 8 GiB
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 16 > ((size_t)1 << 30)) arena_soft_words = std::min(arena_soft_words * 4, free_b / 16 / 4 * 4);
+            if (const char *ev = getenv("STCSP_ARENA_SOFT_MB")) if (atoi(ev) > 0) arena_soft_words = (size_t)atoi(ev) * ((1u << 20) / 4);  // tests: force the batch to shrink
         }
         chunk_r = chunk_r0 = std::max(1, (batch + R - 1) / R);
         HIPCHK(d_ctl.alloc(L.words));
@@ -397,7 +398,7 @@ struct stcsp_engine {
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
-        HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : (size_t)8 * R * chunk_r * ctx.NS));
+        HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : std::min((size_t)8 * R * chunk_r * ctx.NS, std::max(arena_soft_words, (size_t)64 * R * ctx.NS))));
         HIPCHK(d_plan.alloc(1));
         HIPCHK(d_ctx.alloc(1));
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));

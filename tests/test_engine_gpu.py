@@ -181,3 +181,21 @@ def test_engine_array_validity_semantics(stcsp, RefOracle):
         e = stcsp.Engine(m)
         ae, _ = finish(e, e.solve())
         assert ae.canonical() == ao.canonical(), text
+
+
+def test_engine_batch_shrinks_at_arena_soft_limit(stcsp, golden, monkeypatch):
+    """An automatic launch batch (256 k nodes) halves itself instead of growing the frontier arena
+    past its soft limit (explosive searches: memory ~ depth x batch); same automaton."""
+    monkeypatch.setenv("STCSP_ARENA_SOFT_MB", "16")
+    rounds = {}
+    for name in ["partialorder_14", "digitinvader5"]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m)
+        r = e.solve()
+        a, _ = finish(e, r)
+        assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
+        assert r.counters.search_nodes == golden[name]["search"]
+        rounds[name] = r.counters.levels
+    monkeypatch.delenv("STCSP_ARENA_SOFT_MB")
+    e = stcsp.Engine(stcsp.Model.from_name("partialorder_14"))
+    assert e.solve().counters.levels < rounds["partialorder_14"]  # the limited run really used smaller rounds
