@@ -17,7 +17,7 @@ enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWS
        ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
        ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED,
        ST_CYC_STAGE, ST_BLOCKS, ST_CYC_FINAL, ST_ROUNDS_FINAL, ST_CYC_BLOCK,
-       ST_CYC_RV_SETUP, ST_CYC_RV_LOOP, ST_CYC_RV_WB, ST_CYC_CLOSE, ST_CYC_LEAF };
+       ST_CYC_RV_SETUP, ST_CYC_RV_LOOP, ST_CYC_RV_WB, ST_CYC_CLOSE, ST_CYC_LEAF, ST_RV_BLOCKS, ST_RV_OPEN, ST_RV_LANES };
 // per-wavefront LDS words behind the block copy: [0] rows examined by the current node's sweeps, [1 + ST_x]
 // the wavefront's work counters of this launch (flushed to the global statistics once per launch)
 constexpr int kLdsStatWords = 12;

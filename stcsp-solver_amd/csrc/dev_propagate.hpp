@@ -103,6 +103,7 @@ struct Dom {
 struct WaveStats {
     unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
     unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0, cyc_close = 0;
+    unsigned rv_blocks = 0, rv_open = 0, rv_lanes = 0;  // STCSP_PHASES: blocks, open variables, tuple lanes of the general revisions
     unsigned long long evals = 0;   // wave-uniform: rows looked at by all lanes (sweeps) + tuples of wavefront revisions
 };
 
@@ -417,6 +418,10 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit * mystride : 0);
     ws.revs++;
     ws.wave_revs++;
+#ifdef STCSP_PHASES
+    ws.rv_open += (unsigned)__popcll(lowmask | highmask);
+    ws.rv_lanes += (unsigned)P;
+#endif
     const unsigned nact = (unsigned)P;
     // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
     // value of every high variable appears once, so loose constraints finish here.
@@ -453,6 +458,9 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
         }
         ws.evals += nact;
+#ifdef STCSP_PHASES
+        ws.rv_blocks++;
+#endif
         const unsigned long long sm = __ballot(active && res != 0);
         if (sm) {
             any_sat = true;
@@ -945,6 +953,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_CYC_RV_LOOP, ws.cyc_rv_loop);
         add_stats(c, gw, ST_CYC_RV_WB, ws.cyc_rv_wb);
         add_stats(c, gw, ST_CYC_CLOSE, ws.cyc_close);
+        add_stats(c, gw, ST_RV_BLOCKS, ws.rv_blocks);
+        add_stats(c, gw, ST_RV_OPEN, ws.rv_open);
+        add_stats(c, gw, ST_RV_LANES, ws.rv_lanes);
 #endif
     }
     if (!consistent) {

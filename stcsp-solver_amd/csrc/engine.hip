@@ -859,6 +859,11 @@ struct stcsp_engine {
             fprintf(stderr, "[phases] per wavefront revision (completed ones): setup %.0f, enumeration %.0f, write-back %.0f cycles; %.2f revisions per node\n",
                     (double)tot[ST_CYC_RV_SETUP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_LOOP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_WB] / tot[ST_WAVEREVS],
                     (double)tot[ST_WAVEREVS] / tot[ST_NODES]);
+        if (tot[ST_RV_BLOCKS])
+            fprintf(stderr, "[phases] general wavefront revisions: %.2f tuple blocks, %.2f open variables, %.1f tuple lanes each (%.2f per node incl. fast-path ones)\n",
+                    (double)tot[ST_RV_BLOCKS] / std::max(1.0, (double)tot[ST_RV_LANES] > 0 ? (double)tot[ST_CYC_RV_SETUP] > 0 ? (double)tot[ST_WAVEREVS] : 1.0 : 1.0),
+                    (double)tot[ST_RV_OPEN] / std::max(1.0, (double)tot[ST_WAVEREVS]), (double)tot[ST_RV_LANES] / std::max(1.0, (double)tot[ST_WAVEREVS]),
+                    (double)tot[ST_WAVEREVS] / tot[ST_NODES]);
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: closures of the next arcs %.0f, leaf part of process_node (transition, signature, hash, time shift) %.0f\n",
                     (double)tot[ST_CYC_CLOSE] / tot[ST_NODES], (double)tot[ST_CYC_LEAF] / tot[ST_NODES]);
