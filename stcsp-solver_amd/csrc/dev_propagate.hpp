@@ -258,7 +258,8 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
 template <int DR, bool L>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
-                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc, bool &pruned) {
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc,
+                             const unsigned long long (&pm)[DR], bool &pruned) {
     const unsigned long long t_rv0 = PHASE_NOW();
     (void)t_rv0;
     const int s = C.scope_len;
@@ -313,8 +314,10 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             ws.evals += (unsigned)__popc(Dj);
             if (newD == 0) return false;
             if (newD != Dj) {
-                pruned = true;
                 const int w = p * c.N + (int)rdlane((uint32_t)var, j);
+#pragma unroll
+                for (int q = 0; q < DR; q++)
+                    if ((w >> 6) == q && ((pm[q] >> (w & 63)) & 1ull)) pruned = true;  // a next arc hangs on this word
                 dom.set(w, newD, lane);
                 if (lane == 0) ldom[w] = (int)newD;  // keep the sweep's LDS copy of the block current
                 if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + w * S.iw + lane);
@@ -513,8 +516,13 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         }
         if (newD == 0) return false;
         if (newD != Dj) {
-            pruned = true;
             const int vj = (int)rdlane((uint32_t)var, j);
+            {
+                const int w = p * c.N + vj;
+#pragma unroll
+                for (int q = 0; q < DR; q++)
+                    if ((w >> 6) == q && ((pm[q] >> (w & 63)) & 1ull)) pruned = true;  // a next arc hangs on this word
+            }
             dom.set(p * c.N + vj, newD, lane);
             if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
             if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
@@ -928,7 +936,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         ConDesc C;
         load_con<L>(c, P, icon, C);
         bool pruned = false;
-        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc, pruned);
+        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc, pm, pruned);
         need_close = pruned && S.next_off >= 0;
         ws.cyc_wave += PHASE_NOW() - t_wv;
         if (++guard > (1u << 20)) {
