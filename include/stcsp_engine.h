@@ -257,6 +257,17 @@ int stcsp_engine_counters(stcsp_engine *engine, stcsp_counters *out);
 int stcsp_engine_sets_blob(stcsp_engine *engine, const int32_t **words, int64_t *n_words);
 int stcsp_engine_sets_import(stcsp_engine *engine, const int32_t *words, int64_t n_words);
 
+/* Kernel-granularity check (tests, diagnostics): propagate `count` caller-provided domain blocks
+ * (N*K words each, point-major: word[p*N + v], bit i <=> value lb[v] + i) under constraint set `set`
+ * with the production device code of one search node (the propagation of generalisedArcConsistent,
+ * src/solveralgorithm.cpp:617-706, followed by the classification of solverSolveRe, :738). The blocks are
+ * overwritten by their propagated form; outcome[i] = 0 wiped out, 1 branch node, 2 leaf whose
+ * constraint-set translation is not known yet, 3 leaf. *skipped (may be NULL) receives the number of
+ * revisions the device skipped for their enumeration budget (0 => every block is at its GAC fixpoint).
+ * Unsharded engines, between solves. */
+int stcsp_engine_propagate(stcsp_engine *engine, int32_t set, uint32_t expire, uint32_t *blocks, int64_t count,
+                           int32_t *outcome, int64_t *skipped);
+
 #define STCSP_GID_SHIFT 40
 
 #ifdef __cplusplus

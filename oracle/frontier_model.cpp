@@ -321,7 +321,7 @@ struct Model {
         unsigned long long hh = key_hash(kw.data());
         rec[4] = (uint32_t)hh;
         rec[5] = (uint32_t)(hh >> 32);
-        int owner = (int)((hh >> 40) % (unsigned)opt.world);
+        int owner = key_owner(hh, opt.world, KL, kw[0]);  // device_types.hpp: the root key of a signature-less model stays on shard 0
         outbox[owner].insert(outbox[owner].end(), rec.begin(), rec.end());
         return STCSP_OK;
     }

@@ -197,6 +197,9 @@ def bind_engine_api(lib: C.CDLL, prefix: str = "stcsp_engine") -> None:
         g("sets_import").argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]
     if hasattr(lib, f"{prefix}_postprocess"):
         g("postprocess").argtypes = [C.c_void_p, C.POINTER(PostOptions), C.POINTER(PostResult)]
+    if hasattr(lib, f"{prefix}_propagate"):
+        g("propagate").argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int64)]
 
 
 def hip_lib() -> C.CDLL:
@@ -492,6 +495,18 @@ class Engine(EngineBase):
 
     def __init__(self, model: Model, **opts):
         super().__init__(hip_lib(), model, **opts)
+
+    def propagate(self, blocks, set_index: int = 0, expire: int = 0):
+        """Kernel-granularity check: run the device code of one search node on each row of `blocks`
+        (numpy uint32 [count, N*K]). Returns (propagated blocks, outcome per block, skipped revisions)."""
+        import numpy as np
+        b = np.ascontiguousarray(blocks, dtype=np.uint32).copy()
+        count = b.shape[0]
+        outcome = np.zeros(count, dtype=np.int32)
+        skipped = C.c_int64(0)
+        self._check(self._f("propagate")(self._h, set_index, expire, b.ctypes.data_as(C.POINTER(C.c_uint32)), count,
+                                         outcome.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(skipped)))
+        return b, outcome, skipped.value
 
 
 def merge_shards(results):

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <set>
+#include <string>
 
 namespace stcsp {
 
@@ -147,8 +148,14 @@ int SetManager::register_set(std::unique_ptr<HostSet> s) {
             h *= 1099511628211ull;
         }
         int32_t tag = (int32_t)((h ^ (h >> 31)) & 0x3fffffff);
+        // The tag must depend on the set's content only (shards discover sets in different orders), so a
+        // collision cannot be probed away: it is reported (2^-30 per pair of sets).
         if (idx == 0) tag = 0;  // the initial set is set 0 everywhere
-        while (find_tag(tag) >= 0 || (idx != 0 && tag == 0)) tag = (tag + 1) & 0x3fffffff;
+        else if (tag == 0) tag = 0x3fffffff;
+        if (find_tag(tag) >= 0) {
+            error = "two constraint sets share the content tag " + std::to_string(tag) + " (sharded runs identify sets by a 30-bit content hash)";
+            return STCSP_E_UNSUPPORTED;
+        }
         s->tag = tag;
     } else {
         s->tag = idx;
@@ -204,7 +211,8 @@ int SetManager::init(const stcsp_problem *p, bool sharded_tags) {
         }
     for (int v = 0; v < N; v++)
         if (is_sig[v]) sig_vars.push_back(v);
-    register_set(std::move(s0));
+    const int r0 = register_set(std::move(s0));
+    if (r0 < 0) return r0;
     if (!has_first) sets[0]->self_loop = true;  // no translation at all (solveralgorithm.cpp:755)
     return STCSP_OK;
 }
@@ -261,7 +269,10 @@ int SetManager::transition(int set, const std::vector<int> &first_vals) {
     int found = -1;
     for (size_t i = 0; i < sets.size() && found < 0; i++)
         if (set_eq(*ns, *sets[i])) found = (int)i;
-    if (found < 0) found = register_set(std::move(ns));
+    if (found < 0) {
+        found = register_set(std::move(ns));
+        if (found < 0) return found;
+    }
     sets[set]->trans[first_vals] = found;  // (s may dangle after register_set: re-index)
     return found;
 }
@@ -278,8 +289,6 @@ std::vector<int32_t> SetManager::serialise_set(int set) const {
 int SetManager::import_set(const int32_t *words, size_t n) {
     if (n < 2) return STCSP_E_INVALID;
     int32_t tag = words[0];
-    int found = find_tag(tag);
-    if (found >= 0) return found;
     int ncons = words[1];
     const int32_t *p = words + 2, *end = words + n;
     std::unique_ptr<HostSet> ns(new HostSet());
@@ -288,9 +297,20 @@ int SetManager::import_set(const int32_t *words, size_t n) {
         int rc = push_constraint(*ns, t);
         if (rc != STCSP_OK) return rc;
     }
+    // a known tag must stand for the same content here as on the sending shard
+    const int found = find_tag(tag);
+    if (found >= 0) {
+        if (set_eq(*ns, *sets[found])) return found;
+        error = "constraint-set tag " + std::to_string(tag) + " names different sets on two shards";
+        return STCSP_E_INTERNAL;
+    }
     for (size_t i = 0; i < sets.size(); i++)
-        if (set_eq(*ns, *sets[i])) return (int)i;
+        if (set_eq(*ns, *sets[i])) {
+            error = "constraint set known here under tag " + std::to_string(sets[i]->tag) + ", on the sending shard under " + std::to_string(tag);
+            return STCSP_E_INTERNAL;
+        }
     int idx = register_set(std::move(ns));
+    if (idx < 0) return idx;
     if (sets[idx]->tag != tag) {
         error = "constraint-set tag mismatch between shards";
         return STCSP_E_INTERNAL;

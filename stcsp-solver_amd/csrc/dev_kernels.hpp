@@ -506,6 +506,54 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     }
 }
 
+// ------------------------------------------------------------------ k_probe (tests / diagnostics)
+// process_node on caller-provided blocks: the kernel-granularity check behind stcsp_engine_propagate.
+// One wavefront per block, every item dirty (seed 0); the propagated block and the outcome go back.
+template <int DR, bool L, bool CS>
+__global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__restrict__ cp, uint32_t *blocks, int n, int set, uint32_t expire,
+                                                                  int *outcome) {
+    const Ctx &c = *cp;
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int img_words = (c.stage_words + 3) & ~3;
+    if (img_words) {
+        const uint4 *src = (const uint4 *)c.img;
+        uint4 *dst = (uint4 *)smem;
+        for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
+        __syncthreads();
+    }
+    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
+    int *lds_vals = smem + img_words + wib * per_wave;
+    int *lds_stk = lds_vals + kMaxLowVars * 64;
+    Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
+    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;
+    if (lane < kLdsStatWords) lstat[lane] = 0;
+    for (int gw = blockIdx.x * 4 + wib; gw < n; gw += gridDim.x * 4) {
+        uint32_t *blk = blocks + (size_t)gw * c.NK;
+        Dom<DR> dom;
+#pragma unroll
+        for (int q = 0; q < DR; q++) {
+            const int idx = q * 64 + lane;
+            dom.r[q] = idx < c.NK ? blk[idx] : 0u;
+        }
+        NodeHdr hd;
+        hd.h0 = hd.h1 = 0u;
+        hd.set = rfl(set);
+        hd.seed = 0u;
+        hd.expire = rflu(expire);
+        BranchOut bo;
+        LeafOut<DR> lo;
+        const int oc = process_node<DR, L, CS>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+#pragma unroll
+        for (int q = 0; q < DR; q++) {
+            const int idx = q * 64 + lane;
+            if (idx < c.NK) blk[idx] = dom.r[q];
+        }
+        if (lane == 0) outcome[gw] = oc;
+    }
+    flush_lds_stats(c, lstat, blockIdx.x * 4 + wib, lane);
+}
+
 // ------------------------------------------------------------------ k_persist (experimental, opt-in)
 // STATUS: correct (parity-tested) but slower than the round-based default at full occupancy:
 // measured on partialorder_14, 64 wavefronts run at the round-based per-node cost, 5,120 take

@@ -326,6 +326,11 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             return true;
         }
     }
+#ifdef STCSP_NO_GENERAL
+    if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+    ws.skipped++;
+    return true;
+#endif
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
 
     // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
@@ -1060,7 +1065,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     lo.next_set = next_set;
     lo.next_tag = next_tag;
     lo.new_expire = new_expire;
-    lo.owner = (int)((h >> 40) % (unsigned)c.world);
+    lo.owner = key_owner(h, c.world, c.KL, next_tag);
     // edge label (Edge::values) and the time-advanced block (variableAdvanceOneTimeStep,
     // variable.cpp:94-108: point p <- point p+1, last point <- [lb,ub]), lane-striped
 #pragma unroll

@@ -171,6 +171,14 @@ STCSP_HD unsigned long long key_hash(const uint32_t *key, int kl) {
     return mix_final(h);
 }
 
+// Owner shard of a state key. A model without any signature word (no next/first/fby/until) has one
+// state per constraint set and its root key is the plain (tag 0), which a leaf of set 0 must find
+// again: that key lives where begin() put the root, on shard 0, not where its hash points.
+STCSP_HD int key_owner(unsigned long long h, int world, int kl, uint32_t tag) {
+    if (kl == 1 && tag == 0u) return 0;
+    return (int)((h >> 40) % (unsigned)world);
+}
+
 // record strides in words (all multiples of 4)
 STCSP_HD int node_stride(int N, int K) { return (4 + N * K + 3) & ~3; }
 STCSP_HD int cand_stride(int N, int K, int sig_len) { return (kCandHdr + sig_len + N + N * K + 3) & ~3; }

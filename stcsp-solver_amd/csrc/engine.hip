@@ -199,6 +199,8 @@ struct stcsp_engine {
     int upload_program() {
         int rc = mgr.compile(prog);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
+        // node header word 2 = set ordinal (16 bits) | dirty seed << 16
+        if (prog.sets.size() > 0xffffu) return fail(STCSP_E_UNSUPPORTED, "%zu constraint sets; node records address at most 65535", prog.sets.size());
         // one contiguous image; every section starts on a 16-byte boundary
         std::vector<uint32_t> img;
         ImgOff o{};
@@ -621,6 +623,54 @@ struct stcsp_engine {
             if (compact_sweeps) hipLaunchKernelGGL((k_expand<DRT, false, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
             else hipLaunchKernelGGL((k_expand<DRT, false, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
         }
+    }
+
+    // stcsp_engine_propagate: process_node on caller-provided blocks (k_probe)
+    template <int DRT>
+    void launch_probe(unsigned grid, uint32_t *blocks, int n, int set, uint32_t expire, int *outcome) {
+        const Ctx *cp = (const Ctx *)d_ctx.p;
+        if (img_in_lds) {
+            if (compact_sweeps) hipLaunchKernelGGL((k_probe<DRT, true, true>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
+            else hipLaunchKernelGGL((k_probe<DRT, true, false>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
+        } else {
+            if (compact_sweeps) hipLaunchKernelGGL((k_probe<DRT, false, true>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
+            else hipLaunchKernelGGL((k_probe<DRT, false, false>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
+        }
+    }
+    int propagate(int set, uint32_t expire, uint32_t *blocks, int64_t count, int32_t *outcome, int64_t *skipped) {
+        if (sharded) return fail(STCSP_E_STATE, "propagate is for unsharded engines");
+        if (set < 0 || set >= (int)prog.sets.size() || count < 0 || count > (1 << 24) || !blocks || !outcome)
+            return fail(STCSP_E_INVALID, "propagate: bad arguments (set %d of %zu, count %lld)", set, prog.sets.size(), (long long)count);
+        if (count == 0) return STCSP_OK;
+        HIPCHK(hipSetDevice(device));
+        int rc = flush_ctx();
+        if (rc != STCSP_OK) return rc;
+        DevBuf<uint32_t> d_blk;
+        DevBuf<int> d_out;
+        const size_t words = (size_t)count * ctx.NK;
+        HIPCHK(d_blk.alloc(words));
+        HIPCHK(d_out.alloc((size_t)count));
+        HIPCHK(hipMemcpyAsync(d_blk.p, blocks, words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
+        const unsigned grid = (unsigned)std::min<int64_t>((count + 3) / 4, max_blocks);
+        switch (DR) {
+            case 1: launch_probe<1>(grid, d_blk.p, (int)count, set, expire, d_out.p); break;
+            case 2: launch_probe<2>(grid, d_blk.p, (int)count, set, expire, d_out.p); break;
+            default: launch_probe<4>(grid, d_blk.p, (int)count, set, expire, d_out.p); break;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(blocks, d_blk.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(outcome, d_out.p, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, stream));
+        // a probed leaf may have asked for a constraint-set translation: that request is not part of a solve
+        HIPCHK(hipMemsetAsync(d_ctl.p + L.misc0 + MISC_NMISS * CST, 0, sizeof(uint32_t), stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if ((rc = read_ctl())) return rc;  // device errors (watchdog ...)
+        if (skipped) {
+            stcsp_counters ctr{};
+            if ((rc = read_counters(ctr))) return rc;
+            *skipped = ctr.skipped_revisions;
+        }
+        return STCSP_OK;
     }
 
     int service_misses() {
@@ -1395,6 +1445,9 @@ int stcsp_engine_counters(stcsp_engine *e, stcsp_counters *out) {
     if (!e || !out) return STCSP_E_INVALID;
     if (!e->begun) return e->fail(STCSP_E_STATE, "counters before a solve");
     return e->read_counters(*out);
+}
+int stcsp_engine_propagate(stcsp_engine *e, int32_t set, uint32_t expire, uint32_t *blocks, int64_t count, int32_t *outcome, int64_t *skipped) {
+    return e ? e->propagate(set, expire, blocks, count, outcome, skipped) : STCSP_E_INVALID;
 }
 int stcsp_engine_sets_blob(stcsp_engine *e, const int32_t **words, int64_t *n_words) {
     if (!e || !words || !n_words) return STCSP_E_INVALID;

@@ -11,6 +11,7 @@
 // std::set worklists. O(V+E), once per solve: host plumbing (SURVEY.md section 8f-2 lists the
 // device version as a "next" row).
 #include <algorithm>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -569,6 +570,27 @@ struct Automaton {
             fclose(fp);
             return STCSP_E_INVALID;
         }
+        // the counts must be covered by what is left of the file BEFORE anything is sized from them (a
+        // truncated or hostile header would otherwise ask for hundreds of GB)
+        {
+            const long here = ftell(fp);
+            long size = -1;
+            if (here >= 0 && fseek(fp, 0, SEEK_END) == 0) size = ftell(fp);
+            if (here < 0 || size < here || fseek(fp, here, SEEK_SET) != 0) {
+                fclose(fp);
+                return STCSP_E_INVALID;
+            }
+            const unsigned __int128 left = (unsigned __int128)(size - here);
+            const unsigned __int128 need = (unsigned __int128)h[1] * 11                     // per variable: bounds, flag, name length
+                                           + (unsigned __int128)ns * (4 + 4 + 1 + 4)        // ids, cids, final, outdeg
+                                           + (unsigned __int128)ns * h[2] * 4               // signatures
+                                           + (unsigned __int128)ne * 4                      // dsts
+                                           + (unsigned __int128)ne * h[1] * (h[5] == 1 ? 1 : 4);  // labels
+            if (need > left) {
+                fclose(fp);
+                return STCSP_E_INVALID;
+            }
+        }
         n_vars = (int)h[1];
         sig_len = (int)h[2];
         n_sig_vars = (int)h[3];
@@ -798,12 +820,21 @@ int stcsp_automaton_write_dot(const stcsp_automaton *a, const char *path) { retu
 int stcsp_automaton_write_binary(const stcsp_automaton *a, const char *path) { return a && path ? a->a.write_binary(path) : STCSP_E_INVALID; }
 int stcsp_automaton_read_binary(const char *path, stcsp_automaton **out) {
     if (!path || !out) return STCSP_E_INVALID;
-    stcsp_automaton *h = new stcsp_automaton();
-    h->root_final = 0;
-    int rc = h->a.read_binary(path);
-    if (rc != STCSP_OK) {
+    stcsp_automaton *h = nullptr;
+    try {  // no exception may cross the C boundary
+        h = new stcsp_automaton();
+        h->root_final = 0;
+        int rc = h->a.read_binary(path);
+        if (rc != STCSP_OK) {
+            delete h;
+            return rc;
+        }
+    } catch (const std::bad_alloc &) {
         delete h;
-        return rc;
+        return STCSP_E_NOMEM;
+    } catch (...) {
+        delete h;
+        return STCSP_E_INVALID;
     }
     *out = h;
     return STCSP_OK;

@@ -104,9 +104,12 @@ static int run_once(const Flags &f, bool print_line, double *total) {
 
 int main(int argc, char **argv) {
     Flags f;
+    // Option letters of the reference (getopt string "b:e:cv:l:stk:m:az", src/solver.cpp:211). Short flags
+    // may be grouped (-sa); an option value may be attached (-k3, the only form the reference's own
+    // main() handles, src/stcsp.y:199-206) or be the next argument (-k 3).
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
-        if (a[0] != '-') {
+        if (a[0] != '-' || a[1] == 0) {
             if (!f.file) f.file = a;
             continue;
         }
@@ -114,15 +117,32 @@ int main(int argc, char **argv) {
             f.binary = a + 9;
             continue;
         }
-        switch (a[1]) {
-            case 's': f.print_solution = true; break;
-            case 't': f.testing = true; break;
-            case 'a': f.adv1 = true; break;
-            case 'z': f.adv2 = true; break;
-            case 'k': f.prefix_k = atoi(a + 2); break;
-            case 'm': f.time_limit = atoi(a + 2); break;
-            case 'l': case 'b': case 'e': case 'v': break;  // parsed but unused in the reference too
-            default: fprintf(stderr, "Unknown argument: %c\n", a[1]); return 1;
+        for (const char *q = a + 1; *q; q++) {
+            const char o = *q;
+            if (strchr("bevlkm", o)) {  // takes a value: the rest of this argument, else the next one
+                const char *val = q[1] ? q + 1 : (i + 1 < argc ? argv[++i] : nullptr);
+                if (!val) {
+                    fprintf(stderr, "Option -%c needs a value\n", o);
+                    return 1;
+                }
+                if (o == 'k' || o == 'm') {
+                    char *end = nullptr;
+                    const long n = strtol(val, &end, 10);
+                    if (end == val || *end || n < 0 || n > 1000000 || (o == 'k' && n <= 0)) {
+                        fprintf(stderr, "Invalid argument: -%c %s\n", o, val);
+                        return 1;
+                    }
+                    (o == 'k' ? f.prefix_k : f.time_limit) = (int)n;
+                }
+                break;  // b, e, v, l: parsed but unused in the reference too
+            }
+            switch (o) {
+                case 's': f.print_solution = true; break;
+                case 't': f.testing = true; break;
+                case 'a': f.adv1 = true; break;
+                case 'z': f.adv2 = true; break;
+                default: fprintf(stderr, "Unknown argument: %c\n", o); return 1;
+            }
         }
     }
     if (!f.file) {

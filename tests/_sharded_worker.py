@@ -10,6 +10,16 @@ REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 
 
+def load_model(st, spec, prefix_k=2):
+    """`spec`: an instance name, "file:<path to a .csp>" or "synth:n,d,m,s,seed" (instances.synthetic)."""
+    if spec.startswith("file:"):
+        return st.Model(text=Path(spec[5:]).read_text(), prefix_k=prefix_k)
+    if spec.startswith("synth:"):
+        n, d, m, s, seed = (int(x) for x in spec[6:].split(","))
+        return st.Model(text=st.instances.synthetic(n, d, m, s, seed), prefix_k=prefix_k)
+    return st.Model.from_name(spec, prefix_k=prefix_k)
+
+
 def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
     import torch
     import torch.distributed as dist
@@ -23,7 +33,7 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    m = st.Model.from_name(name, prefix_k=prefix_k)
+    m = load_model(st, name, prefix_k)
     if backend_kind == "fmodel":
         # CPU stand-in for the HIP engine (tests only): oracle/frontier_model.cpp
         lib = C.CDLL(str(REPO / "oracle" / "libstcsp_oracle.so"))
@@ -63,7 +73,7 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         a = st.Automaton(m, res).traverse().renumber()
         out = dict(states=a.n_live_states, edges=a.n_live_edges, sha=a.canonical_sha256(), rounds=rounds,
                    table=res.n_states, dom=res.counters.dominance, nodes=res.counters.search_nodes,
-                   sets=res.n_constraint_sets)
+                   sets=res.n_constraint_sets, fails=res.counters.fails, canonical=a.canonical() if a.n_states <= 4096 else None)
         if backend_kind == "hip-nccl":
             out["stepped_ms"] = stepped_ms
         Path(out_path).write_text(json.dumps(out))

@@ -28,6 +28,11 @@ for line in survey.splitlines():
         gold[name] = dict(var=int(m.group(2)), con=int(m.group(3)), dom=num(m.group(4)), node=num(m.group(5)),
                           fail=num(m.group(6)), search=num(m.group(7)), revisions=num(m.group(8)),
                           validate=num(m.group(9)), states=num(m.group(10)), edges=num(m.group(11)))
+        # the same row records the reference's `-a` run where it was made: "(with `-a`: 46.3, `adver1: 0`, empty body)"
+        a = re.search(r"with `-a`: [\d.,*]+, `adver1: (\d)`, (empty body)?", line)
+        if a:
+            gold[name]["adver1_a"] = int(a.group(1))
+            gold[name]["a_body_empty"] = a.group(2) is not None
 # BASELINE.md golden automata rows: | instance | states | edges | md5 | sha256 |
 for line in baseline.splitlines():
     m = re.match(r"^\| ([a-z0-9_]+) \| ([\d,]+) \| ([\d,]+) \| ([0-9a-f]{32}) \| ([0-9a-f]{64}) \|", line)

@@ -43,9 +43,37 @@ def test_binary_empty_and_corrupt(stcsp, RefOracle, tmp_path):
     raw = p.read_bytes()
     (tmp_path / "bad1.bin").write_bytes(b"NOTMAGIC" + raw[8:])
     (tmp_path / "bad2.bin").write_bytes(raw[: len(raw) // 2])
-    for bad in ("bad1.bin", "bad2.bin", "missing.bin"):
+    # a header that claims 2^32 states / 2^36 edges in a file of a few hundred bytes must be rejected
+    # before anything is allocated from those counts (header: magic 8, u32 x 6, table u64, ns u64, ne u64)
+    import struct
+    hostile = bytearray(raw)
+    struct.pack_into("<QQ", hostile, 8 + 24 + 8, 1 << 32, 1 << 36)
+    (tmp_path / "bad3.bin").write_bytes(bytes(hostile))
+    for bad in ("bad1.bin", "bad2.bin", "bad3.bin", "missing.bin"):
         with pytest.raises(stcsp.StcspError):
             stcsp.Automaton.read_binary(str(tmp_path / bad))
+
+
+def test_cli_option_parsing(stcsp, tmp_path):
+    """Option handling of the stcsp command line (reference getopt string "b:e:cv:l:stk:m:az",
+    src/solver.cpp:211): bad values and unknown letters are rejected before any device is touched."""
+    import subprocess
+    exe = stcsp.CSRC / "stcsp"
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(stcsp.CSRC), "stcsp"], check=True, capture_output=True)
+    f = tmp_path / "m.csp"
+    f.write_text("var x:[0,1];\nx == 1;\n")
+    run = lambda *a: subprocess.run([str(exe), *a], capture_output=True, text=True, timeout=60)  # noqa: E731
+    r = run("-k0", str(f))
+    assert r.returncode == 1 and "Invalid argument" in r.stderr
+    r = run("-k", "abc", str(f))
+    assert r.returncode == 1 and "Invalid argument" in r.stderr
+    r = run("-sq", str(f))
+    assert r.returncode == 1 and "Unknown argument: q" in r.stderr
+    r = run(str(f), "-k")
+    assert r.returncode == 1 and "needs a value" in r.stderr
+    r = run()
+    assert r.returncode == 0 and "No constraints!" in r.stdout
 
 
 def test_dot_format_lines(stcsp, RefOracle, tmp_path):

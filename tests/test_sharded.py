@@ -50,6 +50,72 @@ def test_sharded_driver_gloo_cpu(oracle_lib, golden, tmp_path, world, name):
         assert r["table"] == g["node"]
 
 
+# A model without next/first/fby/until has an EMPTY signature: one state per constraint set, and the
+# leaf of set 0 must return to the root key [tag 0], which lives on shard 0 whatever its hash says
+# (device_types.hpp key_owner). world = 1 gives 1 state / 5 edges; a second "root" on another shard
+# would give 2 states / 10 edges.
+NOSIG = "var x:[0,1];\nvar y:[0,2];\nx <= y;\n"
+# the synthetic family at the shapes the reference-faithful oracle finishes:
+# 16 variables x |D| = 8, m = 95 / 88 / 80 point constraints + 4 next-coupled pairs; these instances
+# exercise failing branches (most shipped examples never fail)
+SYNTH_SMALL = ["synth:16,8,95,4,20261003", "synth:16,8,88,4,20261003", "synth:16,8,80,4,20261003"]
+
+
+def reference_of(st, RefOracle, spec):
+    """Canonical automaton of `spec` by oracle/ref_dfs.cpp (the reference's algorithm restated)."""
+    sys.path.insert(0, str(REPO / "tests"))
+    from _sharded_worker import load_model
+    m = load_model(st, spec)
+    o = RefOracle(m)
+    r = o.solve()
+    a = o.automaton(r).traverse().renumber()
+    return a.canonical(), a.canonical_sha256(), r.counters.dominance
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_empty_signature_gloo_cpu(stcsp, oracle_lib, RefOracle, tmp_path, world):
+    f = tmp_path / "nosig.csp"
+    f.write_text(NOSIG)
+    canon, sha, dom = reference_of(stcsp, RefOracle, f"file:{f}")
+    r = launch(world, f"file:{f}", "fmodel", tmp_path)
+    assert (r["states"], r["edges"]) == (1, 5)
+    assert r["sha"] == sha and r["canonical"] == canon
+    assert r["table"] == 1  # no second root on another shard
+
+
+@pytest.mark.parametrize("world,spec", [(2, SYNTH_SMALL[0]), (3, SYNTH_SMALL[1]), (2, SYNTH_SMALL[2])])
+def test_sharded_synthetic_gloo_cpu(stcsp, oracle_lib, RefOracle, tmp_path, world, spec):
+    canon, sha, dom = reference_of(stcsp, RefOracle, spec)
+    r = launch(world, spec, "fmodel", tmp_path)
+    assert r["sha"] == sha
+    assert r["dom"] == dom
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_empty_signature_hip_one_gpu(stcsp, oracle_lib, RefOracle, tmp_path, world):
+    f = tmp_path / "nosig.csp"
+    f.write_text(NOSIG)
+    canon, sha, dom = reference_of(stcsp, RefOracle, f"file:{f}")
+    r = launch(world, f"file:{f}", "hip", tmp_path)
+    assert (r["states"], r["edges"], r["table"]) == (1, 5, 1)
+    assert r["canonical"] == canon
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec", [(2, SYNTH_SMALL[0]), (3, SYNTH_SMALL[0]), (2, SYNTH_SMALL[1]), (3, SYNTH_SMALL[1]),
+                                        (2, SYNTH_SMALL[2]), (3, SYNTH_SMALL[2])])
+def test_sharded_synthetic_hip_one_gpu(stcsp, oracle_lib, RefOracle, tmp_path, world, spec):
+    """The synthetic family (BASELINE config 4) through the sharded pipeline with 2 and 3 HIP shards on
+    one GPU, at the shapes oracle/ref_dfs.cpp terminates on: canonical text equal to the oracle's."""
+    canon, sha, dom = reference_of(stcsp, RefOracle, spec)
+    r = launch(world, spec, "hip", tmp_path)
+    assert r["sha"] == sha
+    if r["canonical"] is not None:
+        assert r["canonical"] == canon
+    assert r["dom"] == dom
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,name", [(2, "juggling_b4_f5"), (2, "partialorder_10"), (3, "digitinvader3")])
 def test_sharded_hip_engine_one_gpu(golden, tmp_path, world, name):
