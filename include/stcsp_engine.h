@@ -249,6 +249,29 @@ int stcsp_engine_candidate_bytes(const stcsp_engine *engine); /* record stride *
 int stcsp_engine_outbox(stcsp_engine *engine, int peer, void **device_ptr, int64_t *count);
 int stcsp_engine_commit(stcsp_engine *engine, const void *device_records, int64_t count);
 int stcsp_engine_finish(stcsp_engine *engine); /* closes the timed search phase */
+
+/* Frontier redistribution ("load-imbalance-triggered redistribution of branch nodes",
+ * the work unit being the branch case of solverSolveRe, src/solveralgorithm.cpp:911-939). Open search nodes are
+ * self-contained records, so any shard can expand any of them:
+ *
+ *   set_expand_budget(max_rounds, min_open)  expand_local() returns early -- with open nodes left -- once it has
+ *                                            run max_rounds launch rounds AND holds at least min_open open nodes
+ *                                            (0, 0 = run the local frontier dry, the default). This is what lets
+ *                                            the driver see an imbalance, and what makes the start "expand on the
+ *                                            root's shard for a few rounds, then scatter".
+ *   donate(want) -> device ptr, count        removes up to `want` open nodes from the OLDEST end of the local
+ *                                            frontier (the shallowest nodes = the biggest subtrees) and returns them
+ *                                            as fixed-size transfer records (node_bytes() each: src state gid,
+ *                                            constraint-set TAG, until-expire bits, dirty seed, domain block);
+ *                                            valid until the next donate / expand_local
+ *   <driver moves the records: the same all-to-all-v as the candidates>
+ *   adopt(device ptr, count)                 pushes received records onto the local frontier (the sender's
+ *                                            constraint sets must have been imported first: sets_import)
+ */
+int stcsp_engine_set_expand_budget(stcsp_engine *engine, int64_t max_rounds, int64_t min_open);
+int stcsp_engine_node_bytes(const stcsp_engine *engine); /* transfer record stride */
+int stcsp_engine_donate(stcsp_engine *engine, int64_t want, void **device_ptr, int64_t *count);
+int stcsp_engine_adopt(stcsp_engine *engine, const void *device_records, int64_t count);
 /* counters of the last / current solve without exporting the automaton */
 int stcsp_engine_counters(stcsp_engine *engine, stcsp_counters *out);
 /* Constraint-set registry exchange: every shard must know a set before it can open a state that

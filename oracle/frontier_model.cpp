@@ -397,19 +397,68 @@ struct Model {
             return true;
         return false;
     }
+    // expand_local returns early once it has expanded budget_rounds * kRoundNodes nodes and holds >= budget_min_open
+    // open nodes (the engine's launch rounds have no counterpart here; a "round" stands for kRoundNodes expansions)
+    int64_t budget_rounds = 0, budget_min_open = 0;
+    static constexpr int64_t kRoundNodes = 64;
     int expand_local(int64_t *left) {
+        int64_t done = 0;
         while (!open.empty()) {
             if (over_budget()) {
                 truncated = true;
                 open.clear();
                 break;
             }
+            if (budget_rounds > 0 && done >= budget_rounds * kRoundNodes && (int64_t)open.size() >= budget_min_open) break;
             std::vector<uint32_t> node = std::move(open.back());
             open.pop_back();
             int rc = expand(std::move(node));
             if (rc != STCSP_OK) return rc;
+            done++;
         }
         if (left) *left = (int64_t)open.size();
+        return STCSP_OK;
+    }
+    // frontier redistribution: the oldest open nodes leave as transfer records (xfer_stride words each)
+    std::vector<uint32_t> donated;
+    int donate(int64_t want, void **ptr, int64_t *count) {
+        const int TS = xfer_stride(N, K);
+        donated.clear();
+        int64_t n = 0;
+        while (n < want && !open.empty()) {
+            const std::vector<uint32_t> &node = open.front();
+            std::vector<uint32_t> rec(TS, 0u);
+            rec[0] = node[0];
+            rec[1] = node[1];
+            rec[2] = (uint32_t)mgr.sets[node[2] & 0xffffu]->tag;
+            rec[3] = node[3];
+            rec[4] = node[2] >> 16;
+            memcpy(rec.data() + kXferHdr, node.data() + 4, (size_t)NK * 4);
+            donated.insert(donated.end(), rec.begin(), rec.end());
+            open.pop_front();
+            n++;
+        }
+        *ptr = donated.data();
+        *count = n;
+        return STCSP_OK;
+    }
+    int adopt(const uint32_t *recs, int64_t count) {
+        const int TS = xfer_stride(N, K);
+        for (int64_t i = 0; i < count; i++) {
+            const uint32_t *rec = recs + (size_t)i * TS;
+            const int set = mgr.find_tag((int32_t)rec[2]);
+            if (set < 0) {
+                err = "adopted node names an unknown constraint set";
+                return STCSP_E_INTERNAL;
+            }
+            std::vector<uint32_t> node(NS, 0u);
+            node[0] = rec[0];
+            node[1] = rec[1];
+            node[2] = (uint32_t)set;  // (this model revises every item of a node: no dirty seed)
+            node[3] = rec[3];
+            memcpy(node.data() + 4, rec + kXferHdr, (size_t)NK * 4);
+            open.push_back(std::move(node));
+        }
         return STCSP_OK;
     }
     int solve() {
@@ -527,6 +576,14 @@ int stcsp_fmodel_outbox(stcsp_fmodel *h, int peer, void **ptr, int64_t *count) {
     return STCSP_OK;
 }
 int stcsp_fmodel_commit(stcsp_fmodel *h, const void *recs, int64_t count) { return h->m.commit((const uint32_t *)recs, count); }
+int stcsp_fmodel_set_expand_budget(stcsp_fmodel *h, int64_t max_rounds, int64_t min_open) {
+    h->m.budget_rounds = max_rounds;
+    h->m.budget_min_open = min_open;
+    return STCSP_OK;
+}
+int stcsp_fmodel_node_bytes(const stcsp_fmodel *h) { return xfer_stride(h->m.N, h->m.K) * 4; }
+int stcsp_fmodel_donate(stcsp_fmodel *h, int64_t want, void **ptr, int64_t *count) { return h->m.donate(want, ptr, count); }
+int stcsp_fmodel_adopt(stcsp_fmodel *h, const void *recs, int64_t count) { return h->m.adopt((const uint32_t *)recs, count); }
 int stcsp_fmodel_finish(stcsp_fmodel *h) {
     h->m.ctr.seconds_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->m.t0).count();
     return STCSP_OK;

@@ -93,6 +93,8 @@ ENGINE_SYMBOLS = [
     "stcsp_engine_last_error", "stcsp_engine_begin", "stcsp_engine_expand_local",
     "stcsp_engine_candidate_bytes", "stcsp_engine_outbox", "stcsp_engine_commit", "stcsp_engine_finish",
     "stcsp_engine_counters", "stcsp_engine_sets_blob", "stcsp_engine_sets_import", "stcsp_engine_postprocess",
+    "stcsp_engine_propagate", "stcsp_engine_set_expand_budget", "stcsp_engine_node_bytes", "stcsp_engine_donate",
+    "stcsp_engine_adopt",
 ]
 HOST_SYMBOLS = [
     "stcsp_model_load_file", "stcsp_model_load_text", "stcsp_model_problem", "stcsp_model_free",
@@ -191,6 +193,11 @@ def bind_engine_api(lib: C.CDLL, prefix: str = "stcsp_engine") -> None:
         g("outbox").argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         g("commit").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         g("finish").argtypes = [C.c_void_p]
+    if hasattr(lib, f"{prefix}_donate"):
+        g("set_expand_budget").argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        g("node_bytes").argtypes = [C.c_void_p]
+        g("donate").argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        g("adopt").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     if hasattr(lib, f"{prefix}_counters"):
         g("counters").argtypes = [C.c_void_p, C.POINTER(Counters)]
         g("sets_blob").argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64)]
@@ -443,6 +450,21 @@ class EngineBase:
 
     def finish(self):
         self._check(self._f("finish")(self._h))
+
+    def set_expand_budget(self, max_rounds: int, min_open: int):
+        self._check(self._f("set_expand_budget")(self._h, max_rounds, min_open))
+
+    def node_bytes(self) -> int:
+        return self._f("node_bytes")(self._h)
+
+    def donate(self, want: int):
+        """Remove up to `want` of the oldest open nodes; returns (pointer, count) of their transfer records."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._check(self._f("donate")(self._h, want, C.byref(ptr), C.byref(n)))
+        return (ptr.value or 0), n.value
+
+    def adopt(self, ptr: int, count: int):
+        self._check(self._f("adopt")(self._h, C.c_void_p(ptr), count))
 
     def counters(self) -> Counters:
         c = Counters()

@@ -702,8 +702,16 @@ int SetManager::compile(FlatProgram &out) {
                         it = proto[0];
                         for (int k = 0; k < 4; k++) it.idx[k] = it.idx[k] >= 0 ? p * N + c.scope[it.idx[k]] : 0;
                     } else {
+                        // a wavefront-revised item carries what the revision needs of its ConDesc, so that the
+                        // device reads ONE record (a single LDS round trip) before it gathers the scope
                         it.type = IT_WAVE;
                         it.arity = cd.scope_len;
+                        it.idx[0] = cd.scope_off;
+                        it.idx[1] = cd.bitmap_off;
+                        it.idx[2] = cd.stride_off;
+                        it.idx[3] = cd.n_forbidden;
+                        it.toff = cd.code_off;
+                        it.r1 = cd.uses_valid;
                     }
                     it.point = p;
                     it.con = con_abs;

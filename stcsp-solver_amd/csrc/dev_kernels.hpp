@@ -1,5 +1,5 @@
 // dev_kernels.hpp -- the kernels: round-based k_expand with its device-side round bookkeeping,
-// the experimental persistent k_persist, state-table commit (table_commit / k_commit), outbox packing,
+// state-table commit (table_commit / k_commit), outbox packing,
 // rehash and the export kernels. Included by engine.hip only.
 #pragma once
 #include "dev_propagate.hpp"
@@ -7,8 +7,32 @@ namespace stcsp {
 namespace dev {
 // ------------------------------------------------------------------ k_expand (round-based)
 // expand ONE open node (slot `gw` of this round) with one wavefront
-template <int DR, bool L, bool CS>
-__device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk) {
+// The kernel context as the node loops see it: a register copy rebuilt from two VGPRs that hold its words
+// lane-striped (word w in hot[w >> 6], lane w & 63). Reading a field is a v_readlane (a few cycles, no counter
+// to wait for) where the copy in memory costs a scalar load per use -- ~40 per node, each ~200 cycles behind
+// s_waitcnt lgkmcnt(0), which also drains every LDS read in flight. The copy is rebuilt at the top of every
+// node and again before its outputs are written (the empty asm keeps the compiler from merging the rebuilds
+// into one set of 70 scalars that is live, and spilled, across the whole slot).
+#ifndef STCSP_CTX_REBUILDS
+#define STCSP_CTX_REBUILDS 2
+#endif
+constexpr int kCtxWords = (int)(sizeof(Ctx) / 4);
+static_assert(kCtxWords <= 128 && sizeof(Ctx) % 4 == 0, "Ctx must fit two lane-striped registers");
+__device__ __forceinline__ Ctx ctx_from(const uint32_t (&hot)[2]) {
+    uint32_t h0 = hot[0], h1 = hot[1];
+    asm volatile("" : "+v"(h0), "+v"(h1));
+    Ctx cr;
+    uint32_t *dst = (uint32_t *)&cr;
+#pragma unroll
+    for (int w = 0; w < kCtxWords; w++) dst[w] = rdlane(w < 64 ? h0 : h1, w & 63);
+    return cr;
+}
+
+template <int DR, bool L, bool CS, bool LITE>
+__device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk, int *ldom,
+                            WaveEnv<DR> &env) {
+    const Ctx c0 = ctx_from(hot);
+    const Ctx &c = c0;
     const int r = gw % R, i = gw / R;
     const int take_r = kload(c.plan, (int)(offsetof(Plan, take) / 4) + r);
     if (i >= take_r) return;
@@ -18,7 +42,6 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
     // an output region receives from at most max(take) wavefronts
     const int ro = (i + r) % R;
     const CtlLayout L_(c.world);
-    uint32_t *misc = c.ctl + L_.misc0;
     const unsigned long long t_a = PHASE_NOW();
     (void)t_a;
     const uint32_t *node = a.in_base + ((size_t)r * a.in_cap + (size_t)(count_r - 1 - i)) * c.NS;
@@ -69,7 +92,21 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
         hd.seed = rflu(hd.seed);
         hd.expire = rflu(hd.expire);
         const unsigned long long t_p = PHASE_NOW();
-        const int oc = process_node<DR, L, CS>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+#if STCSP_CTX_REBUILDS >= 2
+        int oc;
+        {
+            const Ctx cn = ctx_from(hot);
+            oc = process_node<DR, L, CS, LITE>(cn, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
+        }
+        const Ctx ce = ctx_from(hot);
+        const Ctx &c = ce;
+#elif STCSP_CTX_REBUILDS == 1
+        const Ctx ce = ctx_from(hot);
+        const Ctx &c = ce;
+        const int oc = process_node<DR, L, CS, LITE>(c, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
+#else
+        const int oc = process_node<DR, L, CS, LITE>(c, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
+#endif
         const bool last = step >= chain || __builtin_amdgcn_s_memtime() - t_slot > chain_cycles;
         const unsigned long long t_c = PHASE_NOW();
         (void)t_p;
@@ -95,7 +132,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
             if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], n_out);
             pos = rflu(pos);
             if (pos + n_out > a.out_cap) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+                env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
                 return;
             }
             const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
@@ -115,7 +152,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
             if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
             pos = rflu(pos);
             if (pos + 1 > a.out_cap) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
+                env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
                 return;
             }
             store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
@@ -130,7 +167,7 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
             if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
             pos = rflu(pos);
             if (pos + 1 > a.cand_cap) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_CAND_OVERFLOW);
+                env.err = max(env.err, (unsigned)ERR_CAND_OVERFLOW);
                 return;
             }
             uint32_t *rec = a.cand_base + ((size_t)(lo.owner * R + ro) * a.cand_cap + pos) * c.CS;
@@ -147,13 +184,19 @@ __device__ void expand_node(const Ctx &c, const ExpandArgs &a, const Img<L> &P, 
                 if (idx < c.N) vals[idx] = lo.evals[q];
                 if (idx < c.NK) blk[idx] = lo.nblk[q];
             }
+            STCSP_REJOIN();
             return;
         }
         // commit right here, the leaf's data never leaves the registers
-        CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, gw);
+#ifdef STCSP_X_NOCOMMIT
+        return;
+#endif
+        CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals);
+        if (!co.ok) env.err = max(env.err, co.err);
         if (!(co.ok && co.is_new)) return;
+        env.n_new++;
         if (last) {
-            emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk);
+            env.err = max(env.err, emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk));
             return;
         }
         // the leaf opened a new state: its first node is next in the chain
@@ -435,12 +478,18 @@ __global__ void k_close_segment(Ctx c) {
 // allocator lands a few registers above those limits otherwise and loses a whole wavefront per SIMD;
 // the handful of spills this forces sit in cold paths). Ctx is read through a pointer (scalar loads on demand): passing it by value kept ~130 SGPRs
 // live/spilled and cost a wavefront of occupancy per SIMD.
-template <int DR, bool L, bool CS>
-__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (DR <= 2 ? 4 : 3))) void k_expand(const Ctx *__restrict__ cp) {
+#ifndef STCSP_LITE_WAVES
+#define STCSP_LITE_WAVES 6
+#endif
+#ifndef STCSP_GEN_WAVES
+#define STCSP_GEN_WAVES 4
+#endif
+template <int DR, bool L, bool CS, bool LITE>
+__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_slots = kload(c.plan, (int)(offsetof(Plan, nslots) / 4));
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
     if ((int)blockIdx.x * 4 >= n_slots) return;
@@ -454,28 +503,35 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
+    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
+    int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront, then its counters
     Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
+    // the plan is read through the constant address space (scalar loads): a load through a generic pointer is a
+    // source of divergence to the compiler, and one divergent loop exit makes every value carried round the
+    // slot and chain loops a VGPR
     ExpandArgs a;
     {
-        const Plan *p = c.plan;
-        a.in_base = c.arena + p->in_base;
-        a.in_cap = p->in_cap;
-        a.out_base = c.arena + p->out_base;
-        a.out_cap = p->out_cap;
+        auto pl = [&](size_t off) { return (uint32_t)kload(c.plan, (int)(off / 4)); };
+        auto pl64 = [&](size_t off) { return (unsigned long long)pl(off) | (unsigned long long)pl(off + 4) << 32; };
+        a.in_base = c.arena + pl64(offsetof(Plan, in_base));
+        a.in_cap = pl(offsetof(Plan, in_cap));
+        a.out_base = c.arena + pl64(offsetof(Plan, out_base));
+        a.out_cap = pl(offsetof(Plan, out_cap));
         a.cand_base = c.cand;
-        a.cand_cap = p->cand_cap;
-        a.parity = p->parity;
+        a.cand_cap = pl(offsetof(Plan, cand_cap));
+        a.parity = (int)pl(offsetof(Plan, parity));
     }
     const int total_waves = gridDim.x * 4;
     const unsigned long long t_k1 = PHASE_NOW();
     (void)t_k1;
-    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;  // this wavefront's counters (process_node: lstat_add)
-    if (lane < kLdsStatWords) lstat[lane] = 0;
-    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS>(c, a, P, gw, lane, lds_vals, lds_stk);
-    flush_lds_stats(c, lstat, blockIdx.x * 4 + wib, lane);
+    WaveEnv<DR> env;
+    uint32_t hot[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
+    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, env);
+    flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
     __syncthreads();
 #ifdef STCSP_PHASES
     if (threadIdx.x == 0) {
@@ -509,12 +565,12 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
 // ------------------------------------------------------------------ k_probe (tests / diagnostics)
 // process_node on caller-provided blocks: the kernel-granularity check behind stcsp_engine_propagate.
 // One wavefront per block, every item dirty (seed 0); the propagated block and the outcome go back.
-template <int DR, bool L, bool CS>
+template <int DR, bool L, bool CS, bool LITE>
 __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__restrict__ cp, uint32_t *blocks, int n, int set, uint32_t expire,
                                                                   int *outcome) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int img_words = (c.stage_words + 3) & ~3;
     if (img_words) {
         const uint4 *src = (const uint4 *)c.img;
@@ -522,12 +578,12 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
+    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
+    int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;
     Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
-    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;
-    if (lane < kLdsStatWords) lstat[lane] = 0;
+    WaveEnv<DR> env;
     for (int gw = blockIdx.x * 4 + wib; gw < n; gw += gridDim.x * 4) {
         uint32_t *blk = blocks + (size_t)gw * c.NK;
         Dom<DR> dom;
@@ -543,7 +599,7 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         hd.expire = rflu(expire);
         BranchOut bo;
         LeafOut<DR> lo;
-        const int oc = process_node<DR, L, CS>(c, P, lane, lds_vals, lds_stk, dom, hd, gw, bo, lo);
+        const int oc = process_node<DR, L, CS, LITE>(c, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
 #pragma unroll
         for (int q = 0; q < DR; q++) {
             const int idx = q * 64 + lane;
@@ -551,314 +607,7 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         }
         if (lane == 0) outcome[gw] = oc;
     }
-    flush_lds_stats(c, lstat, blockIdx.x * 4 + wib, lane);
-}
-
-// ------------------------------------------------------------------ k_persist (experimental, opt-in)
-// STATUS: correct (parity-tested) but slower than the round-based default at full occupancy:
-// measured on partialorder_14, 64 wavefronts run at the round-based per-node cost, 5,120 take
-// ~190 ms -- the agent-scope loads of thousands of idle pollers serialise on the ring's hot cache
-// lines (~21 M operations/s whatever the back-off) and the producers' atomics queue behind them.
-// A competitive version needs sharded rings / per-CU wake-ups.
-//
-// Persistent work-queue variant of the search (unsharded runs): no rounds, no host in the loop.
-// Every wavefront runs depth-first: after a bisection it keeps the lower child in registers and
-// puts the upper child on its PRIVATE stack (its own slice of HBM); after a leaf that opened a
-// new state it continues with that state's first node. Work is shared through a bounded
-// multi-producer/multi-consumer ring (sequence-number protocol): a busy wavefront pushes a child
-// there instead of on its private stack while the ring is "hungry", idle wavefronts pop from it.
-// Termination: PQ_PENDING counts tasks (= ring items) that were pushed and are not finished yet;
-// a pusher increments it, the wavefront that popped a task decrements it once the task and all of
-// its private descendants are done; idle wavefronts leave when it is 0. A failed pop touches no
-// counter. Every spin is bounded and a global abort word ends the launch.
-__device__ __forceinline__ uint32_t aldw(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void astw(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <int DR>
-__device__ __forceinline__ void ring_store(const Ctx &c, uint32_t *rec, const NodeHdr &hd, const Dom<DR> &dom, int lane) {
-    // agent-scope (write-through) stores: the record is read by another CU
-    if (lane < 4) astw(&rec[lane], lane == 0 ? hd.h0 : (lane == 1 ? hd.h1 : (lane == 2 ? ((uint32_t)hd.set | (hd.seed << 16)) : hd.expire)));
-#pragma unroll
-    for (int q = 0; q < DR; q++) {
-        int idx = q * 64 + lane;
-        if (idx < c.NK) astw(&rec[4 + idx], dom.r[q]);
-    }
-}
-template <int DR>
-__device__ __forceinline__ void ring_load(const Ctx &c, const uint32_t *rec, NodeHdr &hd, Dom<DR> &dom, int lane) {
-    uint32_t hw = lane < 4 ? aldw(&rec[lane]) : 0u;
-#pragma unroll
-    for (int q = 0; q < DR; q++) {
-        int idx = q * 64 + lane;
-        dom.r[q] = idx < c.NK ? aldw(&rec[4 + idx]) : 0u;
-    }
-    hd.h0 = rdlane(hw, 0);
-    hd.h1 = rdlane(hw, 1);
-    const uint32_t w2 = rdlane(hw, 2);
-    hd.set = (int)(w2 & 0xffffu);
-    hd.seed = w2 >> 16;
-    hd.expire = rdlane(hw, 3);
-}
-
-// push one node record on the shared ring. The producer takes its slot with ONE fetch-add (a
-// CAS loop here turns into an O(contenders^2) retry storm when many wavefronts share at once);
-// the sharing policy keeps the ring far from full, so the slot is normally free at once --
-// otherwise wait (bounded) for the consumer of the previous lap. false = gave up (abort set).
-template <int DR>
-__device__ bool q_push(const Ctx &c, const NodeHdr &hd, const Dom<DR> &dom, int lane) {
-    uint32_t pos = 0;
-    int ok = 1;
-    if (lane == 0) {
-        atomicAdd(&c.pq[PQ_PENDING], 1u);
-        pos = atomicAdd(&c.pq[PQ_TAIL], 1u);
-        unsigned spins = 0;
-        while (aldw(&c.seq[pos & c.qmask]) != pos) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 24)) {
-                atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_QUEUE_FULL);
-                ok = 0;
-                break;
-            }
-        }
-    }
-    if (!rfl(ok)) return false;
-    pos = rflu(pos);
-    ring_store<DR>(c, c.ring + (size_t)(pos & c.qmask) * c.NS, hd, dom, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing lane is in this wavefront
-    if (lane == 0) astw(&c.seq[pos & c.qmask], pos + 1);
-    return true;
-}
-
-// pop one node record; false when the ring looks empty OR another consumer won the race (the
-// caller backs off; no hot retry). No counter is touched either way: the popped task stays
-// counted in PQ_PENDING until its wavefront has finished it.
-template <int DR>
-__device__ bool q_pop(const Ctx &c, NodeHdr &hd, Dom<DR> &dom, int lane) {
-    uint32_t pos = 0;
-    int got = 0;
-    if (lane == 0) {
-        pos = aldw(&c.pq[PQ_HEAD]);
-        if (aldw(&c.seq[pos & c.qmask]) == pos + 1) got = atomicCAS(&c.pq[PQ_HEAD], pos, pos + 1) == pos;
-    }
-    if (!rfl(got)) return false;
-    pos = rflu(pos);
-    ring_load<DR>(c, c.ring + (size_t)(pos & c.qmask) * c.NS, hd, dom, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) astw(&c.seq[pos & c.qmask], pos + c.qmask + 1);  // slot free for the next lap
-    return true;
-}
-
-#ifndef STCSP_PERSIST_WAVES
-#define STCSP_PERSIST_WAVES 5
-#endif
-template <int DR, bool L>
-__global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx *__restrict__ cp) {
-    const Ctx &c = *cp;
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
-    const unsigned long long t_k0 = PHASE_NOW();
-    (void)t_k0;
-    if (img_words) {
-        const uint4 *src = (const uint4 *)c.img;
-        uint4 *dst = (uint4 *)smem;
-        for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
-        __syncthreads();
-    }
-    const int per_wave = (kMaxLowVars + c.stack_slots) * 64 + ((c.NK + kLdsStatWords + 63) & ~63);
-    int *lds_vals = smem + img_words + wib * per_wave;
-    int *lds_stk = lds_vals + kMaxLowVars * 64;
-    Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
-    const int wid = blockIdx.x * 4 + wib;
-    int *lstat = lds_stk + c.stack_slots * 64 + c.NK;  // this wavefront's counters (process_node: lstat_add)
-    if (lane < kLdsStatWords) lstat[lane] = 0;
-    uint32_t *mystack = c.pstack + (size_t)wid * c.pstk_cap * c.NS;
-    const CtlLayout L_(c.world);
-    uint32_t *misc = c.ctl + L_.misc0;
-
-    int sp = 0;            // private stack depth
-    bool have = false;     // a node is in registers
-    bool counted = false;  // this wavefront is counted in PQ_ACTIVE
-    Dom<DR> dom;
-    NodeHdr hd{};
-    unsigned long long dbg_idle = 0, dbg_busy = 0, dbg_t = __builtin_amdgcn_s_memtime();
-    unsigned dbg_push = 0, dbg_pop = 0, dbg_polls = 0, dbg_ppop = 0;
-    unsigned polls = 0, nodes_done = 0;
-    // pollers are staggered: each wavefront starts at its own point of the back-off range
-    unsigned backoff = 1u + ((unsigned)wid * 2654435761u >> 26);  // 1..64 us
-    uint32_t last_tail = 0;
-    bool empty_seen = false;
-    for (;;) {
-        if (!have) {
-            if (sp > 0) {  // next sibling from the private stack (own stores: plain accesses)
-                sp--;
-                dbg_ppop++;
-                const uint32_t *rec = mystack + (size_t)sp * c.NS;
-                uint32_t hw = lane < 4 ? rec[lane] : 0u;
-#pragma unroll
-                for (int q = 0; q < DR; q++) {
-                    int idx = q * 64 + lane;
-                    dom.r[q] = idx < c.NK ? rec[4 + idx] : 0u;
-                }
-                hd.h0 = rdlane(hw, 0);
-                hd.h1 = rdlane(hw, 1);
-                const uint32_t w2 = rdlane(hw, 2);
-                hd.set = (int)(w2 & 0xffffu);
-                hd.seed = w2 >> 16;
-                hd.expire = rdlane(hw, 3);
-                have = true;
-            } else {
-                if (counted) {  // the task I popped (and everything below it that I kept) is done
-                    if (lane == 0) atomicSub(&c.pq[PQ_PENDING], 1u);
-                    counted = false;
-                    unsigned long long now = __builtin_amdgcn_s_memtime();
-                    dbg_busy += now - dbg_t;
-                    dbg_t = now;
-                }
-                // Idle polling must be gentle: thousands of wavefronts hammering the same L2 lines
-                // with agent-scope loads starve the producers. While the tail has not moved since
-                // the ring was last seen empty there is nothing to pop, so ONE load per poll
-                // suffices; polls back off exponentially (1 us .. ~0.2 ms).
-                bool try_pop = true;
-                if (empty_seen) {
-                    uint32_t tl = 0;
-                    if (lane == 0) tl = aldw(&c.pq[PQ_TAIL]);
-                    tl = rflu(tl);
-                    try_pop = tl != last_tail;
-                }
-                dbg_polls++;
-                if (try_pop && q_pop<DR>(c, hd, dom, lane)) {
-                    dbg_pop++;
-                    {
-                        unsigned long long now = __builtin_amdgcn_s_memtime();
-                        dbg_idle += now - dbg_t;
-                        dbg_t = now;
-                    }
-                    counted = true;
-                    have = true;
-                    polls = 0;
-                    backoff = 1u + ((unsigned)(wid + nodes_done) * 2654435761u >> 28);  // 1..16 us after work
-                    empty_seen = false;
-                } else {
-                    if (try_pop || (polls & 7u) == 7u) {
-                        // (a lost pop race also lands here: the check below re-reads head/tail)
-                        // done when no task is pending anywhere
-                        uint32_t act = 0, hd_ = 0, tl = 0, stop = 0;
-                        if (lane == 0) {
-                            act = aldw(&c.pq[PQ_PENDING]);
-                            hd_ = aldw(&c.pq[PQ_HEAD]);
-                            tl = aldw(&c.pq[PQ_TAIL]);
-                            stop = aldw(&c.pq[PQ_ABORT]) | aldw(&misc[MISC_ERROR * CST]);
-                        }
-                        act = rflu(act);
-                        hd_ = rflu(hd_);
-                        tl = rflu(tl);
-                        if (rflu(stop)) break;
-                        if (act == 0) break;
-                        if (hd_ == tl) {
-                            empty_seen = true;
-                            last_tail = tl;
-                        } else {
-                            empty_seen = false;  // somebody is mid-push/pop: look again soon
-                        }
-                    }
-                    if (++polls > (1u << 22)) {  // ~10 minutes of nothing: give up loudly
-                        if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_SPIN);
-                        break;
-                    }
-                    for (unsigned k = 0; k < backoff; k++) __builtin_amdgcn_s_sleep(40);  // ~1 us each
-                    if (backoff < (unsigned)c.park_cap && backoff < kMaxBackoff) backoff <<= 1;
-                    continue;
-                }
-            }
-        }
-        // ---- one search node
-        if ((nodes_done & 63u) == 63u) {  // a pool overflowed / somebody aborted: stop producing
-            uint32_t stop = 0;
-            if (lane == 0) stop = aldw(&c.pq[PQ_ABORT]) | aldw(&misc[MISC_ERROR * CST]);
-            if (rflu(stop)) break;
-        }
-        BranchOut bo;
-        LeafOut<DR> lo;
-        const int oc = process_node<DR, L, false>(c, P, lane, lds_vals, lds_stk, dom, hd, wid + (int)nodes_done, bo, lo);
-        nodes_done++;
-        if (oc == OC_FAIL) {
-            have = false;
-        } else if (oc == OC_BRANCH) {
-            // upper child: shared ring while it is hungry (or my stack is full), else private stack
-            Dom<DR> up = dom;
-            up.set(bo.bvar, bo.D & ~bo.lowmask, lane);
-            NodeHdr uh = hd;
-            uh.seed = (uint32_t)(bo.bvar + 1);
-            bool shared = sp >= c.pstk_cap;
-            if (!shared && ((nodes_done & 3u) == 0 || nodes_done < 32u)) {
-                // share only while there are idle wavefronts that the ring cannot feed yet:
-                // in steady state (everybody busy) nothing goes through the shared words at all
-                int want = 0;
-                if (lane == 0) {
-                    const int ql = (int)(aldw(&c.pq[PQ_TAIL]) - aldw(&c.pq[PQ_HEAD]));
-                    const int busy = (int)aldw(&c.pq[PQ_PENDING]) - ql;  // tasks held by wavefronts
-                    want = ql < c.hungry - busy;                         // hungry = wavefronts in the grid
-
-                }
-                shared = rfl(want) != 0;
-            }
-            if (shared) shared = q_push<DR>(c, uh, up, lane);
-            if (shared) dbg_push++;
-            if (!shared) {
-                if (sp >= c.pstk_cap) {
-                    if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_QUEUE_FULL);
-                    break;
-                }
-                store_node<DR>(mystack + (size_t)sp * c.NS, c, uh.h0, uh.h1, (uint32_t)uh.set | (uh.seed << 16), uh.expire, up, lane);
-                sp++;
-            }
-            // continue with the lower child in registers
-            dom.set(bo.bvar, bo.D & bo.lowmask, lane);
-            hd.seed = (uint32_t)(bo.bvar + 1);
-            have = true;
-        } else if (oc == OC_MISS) {
-            uint32_t pi = 0;
-            if (lane == 0) pi = atomicAdd(&c.pq[PQ_PARKED], 1u);
-            pi = rflu(pi);
-            if ((int)pi >= c.park_cap) {
-                if (lane == 0) atomicMax(&c.pq[PQ_ABORT], (uint32_t)AB_PARK_FULL);
-                break;
-            }
-            store_node<DR>(c.parked + (size_t)pi * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
-            have = false;
-        } else {
-            const int ro = (wid + (int)nodes_done) % R;
-            CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals, wid);
-            if (!co.ok) break;  // pool overflow: MISC_ERROR is set
-            if (co.is_new) {
-                // new state: go on with its first node right here
-                const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
-                hd.h0 = (uint32_t)gid;
-                hd.h1 = (uint32_t)(gid >> 32);
-                hd.set = co.set;
-                hd.seed = 0;
-                hd.expire = lo.new_expire;
-#pragma unroll
-                for (int q = 0; q < DR; q++) dom.r[q] = lo.nblk[q];
-                have = true;
-            } else {
-                have = false;
-            }
-        }
-    }
-    if (counted && lane == 0) atomicSub(&c.pq[PQ_PENDING], 1u);
-    flush_lds_stats(c, lstat, wid, lane);
-    if (lane == 0) {
-        dbg_idle += __builtin_amdgcn_s_memtime() - dbg_t;
-        add_stats(c, wid, ST_QPUSH, dbg_push);
-        add_stats(c, wid, ST_QPOP, dbg_pop);
-        add_stats(c, wid, ST_POLLS, dbg_polls);
-        add_stats(c, wid, ST_IDLE_CYC, dbg_idle);
-        add_stats(c, wid, ST_BUSY_CYC, dbg_busy);
-        add_stats(c, wid, ST_PSTACK_POP, dbg_ppop);
-        add_stats(c, wid, ST_WAVES_WORKED, nodes_done ? 1 : 0);
-    }
+    flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
 }
 
 // ------------------------------------------------------------------ commit
@@ -868,7 +617,7 @@ __global__ __launch_bounds__(256, STCSP_PERSIST_WAVES) void k_persist(const Ctx 
 // (reference src/graph.cpp:14-38, 78-89, 108-123).
 template <int DR>
 __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, unsigned long long h, uint32_t s0, uint32_t s1,
-                                  int set, uint32_t tag, const uint32_t (&vals)[DR], int stat_slot) {
+                                  int set, uint32_t tag, const uint32_t (&vals)[DR]) {
     const CtlLayout L(c.world);
     uint32_t *misc = c.ctl + L.misc0;
     CommitOut out;
@@ -876,6 +625,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
     out.is_new = false;
     out.ok = false;
     out.set = set;
+    out.err = 0;
     const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
     uint32_t pos = (uint32_t)h & c.slot_mask;
     uint32_t idx = 0;
@@ -902,7 +652,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
             if (lane == 0) ni = atomicAdd(&misc[MISC_NSTATES * CST], 1u);
             ni = rflu(ni);
             if (ni >= c.state_cap) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
+                out.err = ERR_STATE_OVERFLOW;
                 return out;
             }
             if (lane < c.KL) __hip_atomic_store(&c.state_keys[(size_t)ni * c.KL + lane], kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -910,6 +660,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(&c.slots[pos], ((unsigned long long)htag << 32) | ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            STCSP_REJOIN();
             idx = ni;
             is_new = true;
             break;
@@ -922,7 +673,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
                 if (lane == 0) t = __hip_atomic_load(&c.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lo = rflu((uint32_t)t);
                 if (++spins > (1u << 22)) {
-                    if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_TABLE_SPIN);
+                    out.err = ERR_TABLE_SPIN;
                     return out;
                 }
             }
@@ -937,14 +688,14 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
         }
         pos = (pos + 1) & c.slot_mask;
         if (probes > c.slot_mask) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_STATE_OVERFLOW);
+            out.err = ERR_STATE_OVERFLOW;
             return out;
         }
     }
     // edge record: src (global id), dst (local index), label = time-0 value of every variable
     e = rflu(e);
     if (e >= c.edge_cap) {
-        if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_EDGE_OVERFLOW);
+        out.err = ERR_EDGE_OVERFLOW;
         return out;
     }
     uint32_t *er = c.edges + ((size_t)ro * c.edge_cap + e) * c.ES;
@@ -954,6 +705,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
         int k = q * 64 + lane;
         if (k < c.N) er[4 + k] = vals[q];
     }
+    STCSP_REJOIN();
     out.idx = idx;
     out.is_new = is_new;
     out.ok = true;
@@ -962,28 +714,24 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
             for (int t = 0; t < c.nsets && set < 0; t++)
                 if ((uint32_t)kload(c.img, c.o.sets + t * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = t;
             if (set < 0) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_UNKNOWN_SET);
+                out.err = ERR_UNKNOWN_SET;
                 out.ok = false;
             }
         }
         out.set = set;
-        if (lane == 0) add_stats(c, stat_slot, ST_NEWSTATES, 1);
     }
     return out;
 }
 
 // new state: open its first search node in the round's output segment
 template <int DR>
-__device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
-                                const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]) {
+__device__ unsigned emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
+                                    const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]) {
     const CtlLayout L(c.world);
     uint32_t np = 0;
     if (lane == 0) np = atomicAdd(&c.ctl[L.out(parity, ro)], 1u);
     np = rflu(np);
-    if (np + 1 > out_cap) {
-        if (lane == 0) atomicMax(&c.ctl[L.misc0 + MISC_ERROR * CST], (uint32_t)ERR_OUT_OVERFLOW);
-        return;
-    }
+    if (np + 1 > out_cap) return ERR_OUT_OVERFLOW;
     uint32_t *dst = out_base + ((size_t)ro * out_cap + np) * c.NS;
     const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
     if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)co.set : expire));
@@ -992,12 +740,14 @@ __device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_ba
         int k = q * 64 + lane;
         if (k < c.NK) dst[4 + k] = blk[q];
     }
+    STCSP_REJOIN();
+    return 0u;
 }
 
 // ------------------------------------------------------------------ k_commit (sharded runs)
 template <int DR>
 __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long gw = (long long)blockIdx.x * 4 + wib;
     if (gw >= a.total) return;
     const int ro = (int)(gw % R);  // cursor shard for this wavefront's outputs (edge record, new node)
@@ -1017,8 +767,13 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
         vals[q] = k < c.N ? pv[k] : 0u;
         blk[q] = k < c.NK ? pb[k] : 0u;
     }
-    CommitOut co = table_commit<DR>(c, lane, ro, kw, h, s0, s1, -1, tag, vals, (int)(gw & 0x7fffffff));
-    if (co.ok && co.is_new) emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk);
+    CommitOut co = table_commit<DR>(c, lane, ro, kw, h, s0, s1, -1, tag, vals);
+    unsigned err = co.ok ? 0u : co.err;
+    if (co.ok && co.is_new) {
+        if (lane == 0) add_stats(c, (int)(gw & 0x7fffffff), ST_NEWSTATES, 1);
+        err = emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk);
+    }
+    if (err && lane == 0) atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)err);
 }
 
 // gather the R regions of one owner's outbox into a contiguous array (for the all-to-all)
@@ -1041,6 +796,64 @@ __global__ void k_pack(const uint32_t *cand_base, uint32_t cand_cap, int CS, con
         while (recno >= pref[r + 1]) r++;
         dst[w] = cand_base[((size_t)r * cand_cap + (recno - pref[r])) * CS + off];
     }
+}
+
+// ------------------------------------------------------------------ frontier redistribution (sharded runs)
+// k_donate: the top `take[r]` records of every region of ONE frontier segment leave as transfer records
+// (device_types.hpp xfer_stride: constraint set named by tag, dirty seed in a word of its own); the segment's
+// counts and the open-node total of the device plan are reduced by what left. One wavefront per record.
+struct DonateArgs {
+    unsigned long long seg_base;  // word offset of the segment in the arena
+    unsigned seg_cap;
+    int seg;                      // its index in the plan's segment stack
+    int count[R], take[R];
+    uint32_t pref[R + 1];         // prefix sums of take[]
+};
+__global__ __launch_bounds__(256) void k_donate(Ctx c, DonateArgs a, uint32_t *out) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t gw = blockIdx.x * 4 + wib;
+    if (blockIdx.x == 0 && threadIdx.x < R) {  // account for what leaves
+        c.plan->stack[a.seg].count[threadIdx.x] = a.count[threadIdx.x] - a.take[threadIdx.x];
+        if (threadIdx.x == 0) c.plan->open_total -= (long long)a.pref[R];
+    }
+    if (gw >= a.pref[R]) return;
+    int r = 0;
+#pragma unroll
+    for (int step = R / 2; step >= 1; step >>= 1)
+        if (gw >= a.pref[r + step]) r += step;
+    const uint32_t i = gw - a.pref[r];
+    const uint32_t *node = c.arena + a.seg_base + ((size_t)r * a.seg_cap + (size_t)(a.count[r] - 1 - (int)i)) * c.NS;
+    const int TS = xfer_stride(c.N, c.K);
+    uint32_t *rec = out + (size_t)gw * TS;
+    const uint32_t w2 = node[2];
+    const uint32_t tag = (uint32_t)kload(c.img, c.o.sets + (int)(w2 & 0xffffu) * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
+    if (lane < kXferHdr) rec[lane] = lane == 0 ? node[0] : (lane == 1 ? node[1] : (lane == 2 ? tag : (lane == 3 ? node[3] : (lane == 4 ? w2 >> 16 : 0u))));
+    for (int k = lane; k < c.NK; k += 64) rec[kXferHdr + k] = node[4 + k];
+}
+// k_adopt: received transfer records become open nodes of the segment k_open_segment has just opened
+__global__ __launch_bounds__(256) void k_adopt(Ctx c, const uint32_t *recs, long long total) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const long long gw = (long long)blockIdx.x * 4 + wib;
+    if (gw >= total) return;
+    const CtlLayout L(c.world);
+    const Plan *p = c.plan;
+    const int TS = xfer_stride(c.N, c.K);
+    const uint32_t *rec = recs + (size_t)gw * TS;
+    const uint32_t tag = rec[2];
+    int set = -1;
+    for (int t = 0; t < c.nsets && set < 0; t++)
+        if ((uint32_t)kload(c.img, c.o.sets + t * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4)) == tag) set = t;
+    const int ro = (int)(gw % R);
+    uint32_t np = 0;
+    if (lane == 0) np = atomicAdd(&c.ctl[L.out(p->parity, ro)], 1u);
+    np = rflu(np);
+    if (set < 0 || np + 1 > p->out_cap) {
+        if (lane == 0) atomicMax(&c.ctl[L.misc0 + MISC_ERROR * CST], (uint32_t)(set < 0 ? ERR_UNKNOWN_SET : ERR_OUT_OVERFLOW));
+        return;
+    }
+    uint32_t *dst = c.arena + p->out_base + ((size_t)ro * p->out_cap + np) * c.NS;
+    if (lane < 4) dst[lane] = lane == 0 ? rec[0] : (lane == 1 ? rec[1] : (lane == 2 ? ((uint32_t)set | rec[4] << 16) : rec[3]));
+    for (int k = lane; k < c.NK; k += 64) dst[4 + k] = rec[kXferHdr + k];
 }
 
 // re-insert every state into a larger table
@@ -1097,24 +910,45 @@ __global__ void k_post_kill(EdgeView v, uint8_t *alive, const uint8_t *fail, uin
         atomicSub(&outdeg[er[0]], 1u);
     }
 }
+// Compaction of the live edges into the structure-of-arrays result (a streaming pass: HBM-bound). One
+// wavefront takes 64 consecutive raw records; its live ones get consecutive output slots (one atomic per
+// wavefront), so their labels form ONE contiguous span of nlive * N words that the lanes write word by word
+// (consecutive lanes -> consecutive addresses) while reading the source records through a rank -> record
+// table in LDS (consecutive lanes read consecutive label words of one record).
 __global__ __launch_bounds__(256) void k_post_compact(EdgeView v, const uint8_t *alive, uint32_t *counter, long long *osrc,
                                                        long long *odst, int32_t *oval) {
-    __shared__ uint32_t wcount[4], base;
+    __shared__ unsigned long long tab[4][64];  // per wavefront: word offset of the record of live rank r
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const bool live = e < v.pref[R] && alive[e];
     const unsigned long long m = __ballot(live);
-    if (lane == 0) wcount[wib] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) base = atomicAdd(counter, wcount[0] + wcount[1] + wcount[2] + wcount[3]);
-    __syncthreads();
-    if (!live) return;
-    uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wib; w++) pos += wcount[w];
-    const uint32_t *er = edge_at(v, e);
-    osrc[pos] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
-    odst[pos] = (long long)er[2];
-    for (int k = 0; k < v.N; k++) oval[(size_t)pos * v.N + k] = (int32_t)er[4 + k];
+    const int nlive = __popcll(m);
+    if (nlive == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, (uint32_t)nlive);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (live) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t *er = edge_at(v, e);
+        tab[wib][rank] = (unsigned long long)(er - v.edges);
+        osrc[base + rank] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
+        odst[base + rank] = (long long)er[2];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int N = v.N, total = nlive * N;
+    const int q64 = 64 / N, r64 = 64 % N;
+    int r = lane / N, k = lane - r * N;
+    int32_t *out = oval + (size_t)base * N;
+    for (int w = lane; w < total; w += 64) {
+        out[w] = (int32_t)v.edges[tab[wib][r] + 4 + k];
+        r += q64;
+        k += r64;
+        if (k >= N) {
+            k -= N;
+            r++;
+        }
+    }
 }
 
 }  // namespace dev

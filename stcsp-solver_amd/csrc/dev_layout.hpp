@@ -21,6 +21,11 @@ enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWS
 // per-wavefront LDS words behind the block copy: [0] rows examined by the current node's sweeps, [1 + ST_x]
 // the wavefront's work counters of this launch (flushed to the global statistics once per launch)
 constexpr int kLdsStatWords = 12;
+// LDS words of one wavefront: [lane-enumerated values | expression stack] (general revisions only) + the
+// AND-accumulator copy of the block + the counters. LITE kernels (no general revision) keep the last part only.
+__host__ __device__ inline int wave_scratch_words(int NK, int stack_slots, bool lite) {
+    return (lite ? 0 : (kMaxLowVars + stack_slots) * 64) + ((NK + kLdsStatWords + 63) & ~63);
+}
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
@@ -66,50 +71,41 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
 
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
-        arr_off, words;
+        arr_off, code, words;
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };
 
 struct Ctx {
+    // ---- words 0..63: what the node loops of k_expand read (they see the context through a lane-striped
+    // register copy, dev_kernels.hpp ctx_from: one VGPR covers these)
     int N, K, NK, NS, CS, ES, KL, sig_len, n_sig, n_until_cons, world, rank, nsets, stack_slots;
-    int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
     int sharded;  // leaves emit successor candidates for their owner (world > 1, or STCSP_F_STEPPED) instead of committing in place
+    int stage_words;  // image words every workgroup copies into LDS: o.words (whole image), a prefix of whole hot sections, or 0
     // the compiled program: one contiguous image of 32-bit words (sections at the offsets in `o`),
     // staged into LDS by every workgroup of k_expand when it fits; the bytecode and the
     // user arrays (potentially large) stay in global memory
     const uint32_t *img;
     ImgOff o;
-    int stage_words;  // image words every workgroup copies into LDS: o.words (whole image), a prefix of whole hot sections, or 0
-    const int *code;
-    const int *arr_data;
-    unsigned long long *slots;
     uint32_t slot_mask;
+    unsigned long long *slots;
     uint32_t *state_keys;
     uint32_t state_cap;
+    uint32_t edge_cap;  // records per region
     uint32_t *ctl;
     uint32_t *edges;
-    uint32_t edge_cap;  // records per region
-    int *miss;
-    int miss_cap;
-    unsigned long long *stats;
     Plan *plan;
     uint32_t *arena;
     uint32_t *cand;  // outbox [owner][region] x cand_cap records (sharded runs)
-    // persistent mode (k_persist): shared ring of node records + per-wavefront private stacks
-    uint32_t *pq;      // control words, one per 64-byte line: see PQ_*
-    uint32_t *ring;    // qcap node records
-    uint32_t *seq;     // qcap sequence numbers (bounded MPMC queue)
-    uint32_t *pstack;  // [wavefront][pstk_cap] node records
-    uint32_t *parked;  // nodes waiting for a constraint-set translation
-    uint32_t qmask;    // qcap - 1
-    int pstk_cap, park_cap, hungry;
+    int *miss;
+    int miss_cap;
+    int pad0;
+    // ---- beyond word 63: general wavefront revisions and diagnostics only
+    int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
+    const int *code;
+    const int *arr_data;
+    unsigned long long *stats;
 };
-enum { PQ_HEAD = 0, PQ_TAIL = 16, PQ_PENDING = 32, PQ_ABORT = 48, PQ_PARKED = 64, PQ_WORDS = 80 };
-#ifndef STCSP_MAX_BACKOFF
-#define STCSP_MAX_BACKOFF 128
-#endif
-constexpr unsigned kMaxBackoff = STCSP_MAX_BACKOFF;
-enum { AB_NONE = 0, AB_QUEUE_FULL = 1, AB_PARK_FULL = 2, AB_SPIN = 3, AB_DEVICE_ERROR = 4 };
+static_assert(offsetof(Ctx, budget_bitmap) <= 64 * 4, "the node loops' part of Ctx must fit one lane-striped register");
 
 struct ExpandArgs {  // per-round view, read from the device plan by every wavefront
     const uint32_t *in_base;

@@ -16,8 +16,8 @@ struct Img {
     __device__ __forceinline__ int v(int off) const;
     __device__ __forceinline__ uint4 v4(int off) const;  // off % 4 == 0 (sections and records are 16-byte aligned)
     __device__ __forceinline__ int u(int off) const;     // wave-uniform offset -> scalar value
-    // the same for the cold sections (cons, scope, strides, items, tables), which are never part of a
-    // staged prefix: no boundary test on the paths that read them most
+    // the same for the tables section (the last and potentially big one), which is never part of a staged
+    // prefix of a partly staged image: no boundary test on the paths that read it most
     __device__ __forceinline__ int vc(int off) const;
     __device__ __forceinline__ uint4 v4c(int off) const;
     __device__ __forceinline__ int uc(int off) const;
@@ -58,6 +58,12 @@ template <>
 __device__ __forceinline__ uint4 Img<false>::v4c(int off) const { return *(const uint4 *)(p + off); }
 template <>
 __device__ __forceinline__ int Img<false>::uc(int off) const { return kload(p, off); }
+// After a lane-predicated statement (`if (lane < n) store`) that is followed by a return / break / continue the
+// compiler threads the two sides of the predicate straight into the join of the exits: to its uniformity
+// analysis the exit then hangs on a divergent branch, and one divergent loop exit turns every value carried
+// round the node loops into a VGPR (and every branch on them into exec-mask code). A convergent no-op forces
+// the lanes to rejoin first. (tools/uniformity.sh lists the loops with divergent exits.)
+#define STCSP_REJOIN() __builtin_amdgcn_wave_barrier()
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -100,11 +106,33 @@ struct Dom {
 #else
 #define PHASE_NOW() 0ull
 #endif
-struct WaveStats {
-    unsigned revs = 0, wave_revs = 0, sweeps = 0, skipped = 0;
+struct WaveStats {  // STCSP_PHASES build only: cycle shares of one node
     unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0, cyc_close = 0;
-    unsigned rv_blocks = 0, rv_open = 0, rv_lanes = 0;  // STCSP_PHASES: blocks, open variables, tuple lanes of the general revisions
-    unsigned long long evals = 0;   // wave-uniform: rows looked at by all lanes (sweeps) + tuples of wavefront revisions
+    unsigned rv_blocks = 0, rv_open = 0, rv_lanes = 0;  // blocks, open variables, tuple lanes of the general revisions
+};
+
+// What a wavefront keeps across the nodes it expands in one launch:
+//  * the descriptor of the constraint set it last worked under (absolute image offsets, the eager-arc partner
+//    entry of each of its block words, the masks derived from them) -- consecutive nodes of a chain or of a
+//    cursor region nearly always share the set, so the ~20 LDS reads this takes are paid once, not per node;
+//  * its work counters and a sticky error code, which reach global memory once, at the end of the launch
+//    (per-node atomics, even LDS ones by lane 0, are a divergent branch and a wait each).
+// Everything is wave-uniform (SGPRs) unless marked "per lane".
+template <int DR>
+struct WaveEnv {
+    int set = -1;
+    int self_loop = 0, nfirst = 0, first_off = 0, trans_begin = 0, trans_count = 0, nitems = 0, nsmall = 0, iw = 1;
+    int rows_abs = 0;   // the set's [N*K][iw] dirty rows
+    int sweep_abs = 0;  // its packed sweep records
+    int items_abs = 0;  // its ItemDesc records
+    int next_abs = -1;  // its eager-arc partner entries (-1: the set has none)
+    unsigned long long pm[DR] = {};  // block words (bit l = word q*64 + l) that have an eager partner
+    uint32_t smallmask = 0;          // per lane: bits of the lane-revised items in dirty word `lane`
+    uint32_t e0[DR] = {};            // per lane: partner entry 0 of block word q*64 + lane
+    unsigned n_nodes = 0, n_fails = 0, n_leaves = 0, n_requeue = 0, n_revs = 0, n_wave_revs = 0, n_sweeps = 0, n_skipped = 0, n_new = 0;
+    unsigned long long n_evals = 0;
+    uint32_t rows_seen = 0;  // per lane: table rows examined by this lane's sweeps
+    unsigned err = 0;        // MISC_ERROR code
 };
 
 // Evaluate one constraint program on this lane's tuple (the role of solverValidateRe,
@@ -118,14 +146,14 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_val
     bool valid = true;
     uint32_t dead = 0;
     for (;;) {
-        int w = kload(c.code, pc++);
+        int w = P.u(c.o.code + pc++);
         int op = w & 255, arg = w >> 8;
         switch (op) {
             case OP_END: return t;
             case OP_CONST:
                 lds_stk[sp * 64 + lane] = t;
                 sp++;
-                t = kload(c.code, pc++);
+                t = P.u(c.o.code + pc++);
                 break;
             case OP_VAR: {
                 lds_stk[sp * 64 + lane] = t;
@@ -256,16 +284,16 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // scope variable has a supporting tuple (generalised arc consistency on this constraint; the
 // reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
 // Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
-template <int DR, bool L>
-__device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
-                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, uint32_t *ctl_misc,
-                             const unsigned long long (&pm)[DR], bool &pruned) {
+template <int DR, bool L, bool LITE>
+__device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
+                             int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, bool &pruned) {
+    const unsigned long long(&pm)[DR] = S.pm;
     const unsigned long long t_rv0 = PHASE_NOW();
     (void)t_rv0;
     const int s = C.scope_len;
     // per-lane view of scope variable j = lane
     int var = 0;
-    if (lane < s) var = G.vc(c.o.scope + C.scope_off + lane);
+    if (lane < s) var = G.v(c.o.scope + C.scope_off + lane);
     uint32_t D = dom.gather(p * c.N + var);
     if (lane >= s) D = 0;
     const int n = lane < s ? __popc(D) : 1;
@@ -275,20 +303,28 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     // only when the whole product of the OTHER domains is forbidden, so unless
     // prod(all domains) / (largest domain) <= n_forbidden this revision cannot prune anything.
     if (C.n_forbidden >= 0) {
-        unsigned long long prod = 1;
-        int largest = 1;
-        for (unsigned long long m = __ballot(lane < s && n > 1); m && prod <= (unsigned long long)kFewForbidden * 32u; m &= m - 1) {
-            const int nj = (int)rdlane((uint32_t)n, __ffsll((long long)m) - 1);
-            prod *= (unsigned long long)nj;
-            if (nj > largest) largest = nj;
+        const unsigned long long open = __ballot(lane < s && n > 1);
+        const int nopen = __popcll(open);
+        // prod >= 2^nopen and largest <= 32; and any two open variables already give prod >= 2 * largest
+        bool skip = (C.n_forbidden <= 1 && nopen >= 2) || C.n_forbidden == 0 || nopen >= 12 ||
+                    (1u << nopen) > (unsigned)C.n_forbidden * 32u;
+        if (!skip && nopen >= 2) {
+            unsigned long long prod = 1;
+            int largest = 1;
+            for (unsigned long long m = open; m; m &= m - 1) {
+                const int nj = (int)rdlane((uint32_t)n, __ffsll((long long)m) - 1);
+                prod *= (unsigned long long)nj;
+                if (nj > largest) largest = nj;
+            }
+            skip = prod > (unsigned long long)C.n_forbidden * (unsigned long long)largest;
         }
-        if (prod > (unsigned long long)C.n_forbidden * (unsigned long long)largest) {
+        if (skip) {
             if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
             return true;
         }
     }
     const bool use_bitmap = C.bitmap_off >= 0;
-    const int mystride = (use_bitmap && lane < s) ? G.vc(c.o.strides + C.stride_off + lane) : 0;
+    const int mystride = (use_bitmap && lane < s) ? G.v(c.o.strides + C.stride_off + lane) : 0;
     // Fast path (tuple-bitmap constraints): at most ONE scope variable is not yet fixed -- the usual
     // situation deep in the tree. No tuple enumeration to set up: lane v looks value v of that variable
     // up (one block of <= 32 tuples), or the single tuple is checked when everything is fixed.
@@ -297,12 +333,12 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         if (use_bitmap && (open_vars & (open_vars - 1)) == 0) {
             const int fixed_part = wave_sum((lane < s && n == 1) ? (__ffs((int)D) - 1) * mystride : 0);
             const int tab = c.o.tables + C.bitmap_off;
-            ws.revs++;
-            ws.wave_revs++;
+            S.n_revs++;
+            S.n_wave_revs++;
             if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
             if (!open_vars) {
-                ws.evals += 1;
-                return (((uint32_t)G.vc(tab + (fixed_part >> 5)) >> (fixed_part & 31)) & 1u) != 0;
+                S.n_evals += 1;
+                return ((rflu((uint32_t)G.vc(tab + (fixed_part >> 5))) >> (fixed_part & 31)) & 1u) != 0;  // rfl: a loaded value is divergent to the compiler
             }
             const int j = __ffsll((long long)open_vars) - 1;
             const uint32_t Dj = rdlane(D, j);
@@ -311,7 +347,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             const int bit = fixed_part + lane * strj;
             const bool sat = has && ((((uint32_t)G.vc(tab + (bit >> 5))) >> (bit & 31)) & 1u);
             const uint32_t newD = (uint32_t)__ballot(sat);
-            ws.evals += (unsigned)__popc(Dj);
+            S.n_evals += (unsigned)__popc(Dj);
             if (newD == 0) return false;
             if (newD != Dj) {
                 const int w = p * c.N + (int)rdlane((uint32_t)var, j);
@@ -320,17 +356,20 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
                     if ((w >> 6) == q && ((pm[q] >> (w & 63)) & 1ull)) pruned = true;  // a next arc hangs on this word
                 dom.set(w, newD, lane);
                 if (lane == 0) ldom[w] = (int)newD;  // keep the sweep's LDS copy of the block current
-                if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + w * S.iw + lane);
+                if (lane < S.iw) dirtyw |= (uint32_t)G.v(S.rows_abs + w * S.iw + lane);
                 if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));  // a revision is a fixpoint for its own constraint
             }
             return true;
         }
     }
-#ifdef STCSP_NO_GENERAL
-    if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
-    ws.skipped++;
-    return true;
-#endif
+    if constexpr (LITE) {
+        // LITE kernels are selected for programs whose wavefront-revised constraints can only take the two
+        // exits above (tuple bitmap with at most one violating tuple: engine.hip upload_program); anything
+        // else is skipped, which is sound (a leaf's single tuple is checked by the fast path)
+        if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+        S.n_skipped++;
+        return true;
+    }
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
 
     // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
@@ -409,7 +448,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             total_hi *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)hm) - 1);
         if (total_hi > budget) {
             if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
-            ws.skipped++;
+            S.n_skipped++;
             return true;
         }
     }
@@ -424,8 +463,8 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     // bitmap index contribution of the singleton variables (constant for this revision)
     int base_sum = 0;
     if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit * mystride : 0);
-    ws.revs++;
-    ws.wave_revs++;
+    S.n_revs++;
+    S.n_wave_revs++;
 #ifdef STCSP_PHASES
     ws.rv_open += (unsigned)__popcll(lowmask | highmask);
     ws.rv_lanes += (unsigned)P;
@@ -465,7 +504,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         } else {
             res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
         }
-        ws.evals += nact;
+        S.n_evals += nact;
 #ifdef STCSP_PHASES
         ws.rv_blocks++;
 #endif
@@ -497,7 +536,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
         }
         if (carry) break;  // wrapped around: product exhausted
         if (++iters > (1ull << 22)) {
-            if (lane == 0) atomicMax(&ctl_misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            S.err = max(S.err, (unsigned)ERR_WATCHDOG);
             return false;
         }
     }
@@ -530,7 +569,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
             }
             dom.set(p * c.N + vj, newD, lane);
             if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
-            if (lane < S.iw) dirtyw |= (uint32_t)G.v(c.o.itemrows + S.itemrows_off + (p * c.N + vj) * S.iw + lane);
+            if (lane < S.iw) dirtyw |= (uint32_t)G.v(S.rows_abs + (p * c.N + vj) * S.iw + lane);
         }
     }
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
@@ -544,35 +583,62 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, const SetDesc &S, co
     return true;
 }
 
-template <bool L>
-__device__ __forceinline__ void load_set(const Ctx &c, const Img<L> &P, int set, SetDesc &S) {
-    int *dst = (int *)&S;
+// (Re)load the constraint-set part of the wavefront's environment: one per-lane read of the SetDesc words
+// (broadcast with readlane), then the per-lane pieces derived from it.
+template <int DR, bool L>
+__device__ __forceinline__ void load_env(const Ctx &c, const Img<L> &P, int set, int lane, WaveEnv<DR> &E) {
+    constexpr int W = (int)(sizeof(SetDesc) / 4);
+    const uint32_t w = lane < W ? (uint32_t)P.v(c.o.sets + set * W + lane) : 0u;
+#define STCSP_SD(f) (int) rdlane(w, (int)(offsetof(SetDesc, f) / 4))
+    E.set = set;
+    E.self_loop = STCSP_SD(self_loop);
+    E.nfirst = STCSP_SD(nfirst);
+    E.first_off = STCSP_SD(first_off);
+    E.trans_begin = STCSP_SD(trans_begin);
+    E.trans_count = STCSP_SD(trans_count);
+    E.nitems = STCSP_SD(nitems);
+    E.nsmall = STCSP_SD(nsmall);
+    E.iw = STCSP_SD(iw);
+    const int item_begin = STCSP_SD(item_begin), next_off = STCSP_SD(next_off);
+    E.rows_abs = c.o.itemrows + STCSP_SD(itemrows_off);
+#undef STCSP_SD
+    E.sweep_abs = c.o.sweep + item_begin * 4;
+    E.items_abs = c.o.items + item_begin * (int)(sizeof(ItemDesc) / 4);
+    E.next_abs = next_off >= 0 ? c.o.nextpart + next_off : -1;
+    {
+        const int left = E.nsmall - lane * 32;
+        E.smallmask = (lane < E.iw && left > 0) ? (left >= 32 ? 0xffffffffu : ((1u << left) - 1u)) : 0u;
+    }
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(SetDesc) / 4); i++) dst[i] = P.u(c.o.sets + set * (int)(sizeof(SetDesc) / 4) + i);
+    for (int q = 0; q < DR; q++) {
+        const int idx = q * 64 + lane;
+        E.e0[q] = (E.next_abs >= 0 && idx < c.NK) ? (uint32_t)P.v(E.next_abs + idx * 2) : 0u;
+        E.pm[q] = __ballot(E.e0[q] != 0);
+    }
 }
-template <bool L>
-__device__ __forceinline__ void load_con(const Ctx &c, const Img<L> &P, int idx, ConDesc &C) {
-    int *dst = (int *)&C;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(ConDesc) / 4); i++) dst[i] = P.uc(c.o.cons + idx * (int)(sizeof(ConDesc) / 4) + i);
-}
-
 __device__ __forceinline__ void add_stats(const Ctx &c, int gw, int which, unsigned long long v) {
     if (v) atomicAdd(&c.stats[(gw % kStatSlots) * kStatWords + which], v);
 }
-// The per-node work counters (ST_NODES .. ST_SKIPPED) are summed in LDS by lane 0 and reach the global
-// statistics once per wavefront and launch: seven global atomics per node on 64 hot lines would sit in
-// vmcnt in front of the next node's loads.
-__device__ __forceinline__ void lstat_add(int *lstat, int which, unsigned v) {
-    if (v) atomicAdd((unsigned *)&lstat[1 + which], v);
-}
-__device__ __forceinline__ void flush_lds_stats(const Ctx &c, int *lstat, int slot, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane <= ST_SKIPPED) {
-        const unsigned v = (unsigned)lstat[1 + lane];
-        if (v) atomicAdd(&c.stats[(slot % kStatSlots) * kStatWords + lane], (unsigned long long)v);
-        lstat[1 + lane] = 0;
+// End of a launch: the wavefront's counters and its error code reach global memory (lane k adds counter k).
+template <int DR>
+__device__ __forceinline__ void flush_env(const Ctx &c, WaveEnv<DR> &E, int slot, int lane) {
+    const unsigned rows = (unsigned)wave_sum((int)E.rows_seen);  // every lane is active here
+    unsigned long long v = 0;
+    switch (lane) {
+        case ST_NODES: v = E.n_nodes; break;
+        case ST_FAILS: v = E.n_fails; break;
+        case ST_LEAVES: v = E.n_leaves; break;
+        case ST_REVS: v = E.n_revs; break;
+        case ST_EVALS: v = E.n_evals + rows; break;
+        case ST_REQUEUE: v = E.n_requeue; break;
+        case ST_NEWSTATES: v = E.n_new; break;
+        case ST_WAVEREVS: v = E.n_wave_revs; break;
+        case ST_SWEEPS: v = E.n_sweeps; break;
+        case ST_SKIPPED: v = E.n_skipped; break;
+        default: break;
     }
+    if (v) atomicAdd(&c.stats[(slot % kStatSlots) * kStatWords + lane], v);
+    if (E.err && lane == 0) atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)E.err);
 }
 
 template <int DR>
@@ -584,6 +650,7 @@ __device__ __forceinline__ void store_node(uint32_t *dst, const Ctx &c, uint32_t
         int idx = q * 64 + lane;
         if (idx < c.NK) dst[4 + idx] = dom.r[q];
     }
+    STCSP_REJOIN();
 }
 
 enum Outcome : int { OC_FAIL = 0, OC_BRANCH, OC_MISS, OC_LEAF };
@@ -610,24 +677,24 @@ struct CommitOut {
     uint32_t idx;  // local state index
     bool is_new, ok;
     int set;
+    unsigned err;  // !ok: the MISC_ERROR code (the caller reports it)
 };
 template <int DR>
 __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, unsigned long long h, uint32_t s0, uint32_t s1,
-                                  int set, uint32_t tag, const uint32_t (&vals)[DR], int stat_slot);
+                                  int set, uint32_t tag, const uint32_t (&vals)[DR]);
 template <int DR>
-__device__ void emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
-                                const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]);
+__device__ unsigned emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
+                                    const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]);
 
 // ------------------------------------------------------------------ one search node
 // Propagate the block in `dom` to its fixpoint under the node's constraint set and classify the
 // node like solverSolveRe does: failed / branch / leaf (or "miss": a leaf whose constraint-set
 // translation the host has not provided yet). Outputs stay in registers; the callers (the
-// round-based k_expand and the persistent k_persist) decide where children and leaves go.
+// round-based k_expand, the probe kernel) decide where children and leaves go.
 // OR the dirty rows of every block word in `cm` (bit l = word q*64 + l changed) into the lane-striped
 // dirty mask, four words per trip (independent reads).
 template <bool L>
-__device__ __forceinline__ void mark_dirty_rows(const Ctx &c, const Img<L> &P, const SetDesc &S, int q, unsigned long long cm, int lane,
-                                                uint32_t &dirtyw) {
+__device__ __forceinline__ void mark_dirty_rows(const Img<L> &P, int rows_abs, int iw, int q, unsigned long long cm, int lane, uint32_t &dirtyw) {
     while (cm) {
         const int l0 = __ffsll((long long)cm) - 1;
         cm &= cm - 1;
@@ -637,10 +704,10 @@ __device__ __forceinline__ void mark_dirty_rows(const Ctx &c, const Img<L> &P, c
         cm &= cm - 1;
         const int l3 = cm ? __ffsll((long long)cm) - 1 : l0;
         cm &= cm - 1;
-        if (lane < S.iw) {
-            const int rows = c.o.itemrows + S.itemrows_off + lane;
-            const uint32_t r0 = (uint32_t)P.v(rows + (q * 64 + l0) * S.iw), r1 = (uint32_t)P.v(rows + (q * 64 + l1) * S.iw);
-            const uint32_t r2 = (uint32_t)P.v(rows + (q * 64 + l2) * S.iw), r3 = (uint32_t)P.v(rows + (q * 64 + l3) * S.iw);
+        if (lane < iw) {
+            const int rows = rows_abs + lane;
+            const uint32_t r0 = (uint32_t)P.v(rows + (q * 64 + l0) * iw), r1 = (uint32_t)P.v(rows + (q * 64 + l1) * iw);
+            const uint32_t r2 = (uint32_t)P.v(rows + (q * 64 + l2) * iw), r3 = (uint32_t)P.v(rows + (q * 64 + l3) * iw);
             dirtyw |= r0 | r1 | r2 | r3;
         }
     }
@@ -651,8 +718,8 @@ __device__ __forceinline__ void mark_dirty_rows(const Ctx &c, const Img<L> &P, c
 // nothing changes (one pass for K = 2). Run after every change of the block, so that these arcs are
 // never work items and their prunings do not cost a sweep of their own. Returns false on a wipe-out.
 template <int DR, bool L>
-__device__ bool close_next(const Ctx &c, const Img<L> &P, const SetDesc &S, Dom<DR> &dom, int lane, int *ldom, uint32_t &dirtyw) {
-    const int base = c.o.nextpart + S.next_off;
+__device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, Dom<DR> &dom, int lane, int *ldom, uint32_t &dirtyw) {
+    const int base = S.next_abs;
     // what one entry allows: the partner's domain shifted into this word's value numbering
     auto allowed = [](uint32_t e, uint32_t partner) -> uint32_t {
         if (!e) return 0xffffffffu;
@@ -667,7 +734,7 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const SetDesc &S, Dom<
         for (int q = 0; q < DR; q++) {
             const int idx = q * 64 + lane;
             const bool in = idx < c.NK;
-            const uint32_t e0 = in ? (uint32_t)P.v(base + idx * 2) : 0u;
+            const uint32_t e0 = S.e0[q];
             // gathers are executed by every lane (cross-lane reads need the source lanes active)
             uint32_t nd = dom.r[q] & allowed(e0, dom.gather(e0 ? (int)(e0 & 0xffffu) - 1 : 0));
             if (c.K > 2) {  // a word can sit on both sides of arcs only with more than two time points
@@ -679,7 +746,7 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const SetDesc &S, Dom<
             if (cm) {
                 if (nd != dom.r[q]) ldom[idx] = (int)nd;  // keep the sweeps' LDS copy current
                 dom.r[q] = nd;
-                mark_dirty_rows<L>(c, P, S, q, cm, lane, dirtyw);
+                mark_dirty_rows<L>(P, S.rows_abs, S.iw, q, cm, lane, dirtyw);
                 changed = true;
             }
         }
@@ -690,15 +757,12 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const SetDesc &S, Dom<
     return true;
 }
 
-template <int DR, bool L, bool CS>
-__device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, Dom<DR> &dom,
-                            const NodeHdr &hd, int gw, BranchOut &bo, LeafOut<DR> &lo) {
-    const CtlLayout L_(c.world);
-    uint32_t *misc = c.ctl + L_.misc0;
+template <int DR, bool L, bool CS, bool LITE>
+__device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, int *ldom, Dom<DR> &dom,
+                            const NodeHdr &hd, int gw, WaveEnv<DR> &S, BranchOut &bo, LeafOut<DR> &lo) {
     const int set = hd.set;
     const uint32_t seed = hd.seed, expire = hd.expire;
-    SetDesc S;
-    load_set<L>(c, P, set, S);
+    if (set != S.set) load_env<DR, L>(c, P, set, lane, S);
 
     // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). Work items
     // are (constraint, time point) pairs; the dirty mask is lane-striped (lane w holds word w).
@@ -707,21 +771,16 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     // through an LDS copy (a Jacobi sweep); the remaining items are revised by the whole
     // wavefront one at a time. Monotone propagators: any fair order reaches the same fixpoint.
     WaveStats ws;
-    int *ldom = lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront
     uint32_t dirtyw = 0;
     if (lane < S.iw) {
         if (seed == 0) {
             int left = S.nitems - lane * 32;
             dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
         } else if (seed != 0xffffu) {
-            dirtyw = (uint32_t)P.v(c.o.itemrows + S.itemrows_off + (int)(seed - 1) * S.iw + lane);  // word (0, seed var)
+            dirtyw = (uint32_t)P.v(S.rows_abs + (int)(seed - 1) * S.iw + lane);  // word (0, seed var)
         }
     }
-    uint32_t smallmask = 0;
-    if (lane < S.iw) {
-        int left = S.nsmall - lane * 32;
-        smallmask = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
-    }
+    const uint32_t smallmask = S.smallmask;
     bool consistent = true;
     unsigned guard = 0;
     // LDS copy of the block (AND-accumulator of the sweeps); kept equal to `dom` between sweeps.
@@ -732,20 +791,13 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         int idx = q * 64 + lane;
         if (idx < c.NK) ldom[idx] = (int)dom.r[q];
     }
-    if (lane == 0) ldom[c.NK] = 0;  // rows examined by the sweeps of this node (statistics)
     // the X == next Y arcs that are not items: the parent kept them consistent, the bisection (or the
-    // time shift of a fresh state) may have broken them
-    // pm[q]: block words (bit l = word q*64 + l) that have an eager partner; a closure is only due
-    // when such a word changed (scalar tests from here on)
-    unsigned long long pm[DR];
+    // time shift of a fresh state) may have broken them. S.pm[q]: block words (bit l = word q*64 + l) that
+    // have an eager partner; a closure is only due when such a word changed (scalar tests from here on)
+    const unsigned long long(&pm)[DR] = S.pm;
     bool need_close = false;
-#pragma unroll
-    for (int q = 0; q < DR; q++) {
-        const int idx = q * 64 + lane;
-        pm[q] = S.next_off >= 0 ? __ballot(idx < c.NK && P.v(c.o.nextpart + S.next_off + idx * 2) != 0) : 0ull;
-    }
     if (seed == 0) {
-        need_close = S.next_off >= 0;  // fresh state: the time shift may have broken any arc
+        need_close = S.next_abs >= 0;  // fresh state: the time shift may have broken any arc
     } else if (seed != 0xffffu) {
         const int w = (int)seed - 1;  // the parent bisected time-0 word w and was at its fixpoint otherwise
 #pragma unroll
@@ -767,7 +819,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool lfail = false;
-            ws.sweeps++;
+            S.n_sweeps++;
             // Sets with many small items (the synthetic 64 x 32 family: 1,216) have their dirty items
             // scattered over the item index space -- ~120 dirty per sweep in 19 blocks of 64, six
             // busy lanes per pass. There the dirty bits are compacted first: lane k of pass t takes
@@ -808,9 +860,8 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 }
                 unsigned long long dmask = __ballot(isd);
                 if (!dmask) continue;
-                ws.revs += (unsigned)__popcll(dmask);
                 // the lane's item, unpacked from its 16-byte sweep record (device_types.hpp)
-                const uint4 sw = P.v4(c.o.sweep + (S.item_begin + (isd ? item : 0)) * 4);
+                const uint4 sw = P.v4(S.sweep_abs + (isd ? item : 0) * 4);
                 struct {
                     int idx[4], type, arity, r1, r2, aux, toff;
                 } it;
@@ -842,7 +893,9 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                             int vx = P.v(c.o.var_lb + it.idx[0]) + __ffs((int)D0) - 1, vy = P.v(c.o.var_lb + it.idx[1]) + __ffs((int)D1) - 1;
                             if (vx != 1 && vy != 1) lfail = true;
                         }
-                    } else {
+                    }
+#ifndef STCSP_X_NOTAB
+                    else {
                         // small extensional constraint: one row of allowed word-variable values per
                         // tuple of the other (<= 3) variables; scan the rows of the current product
                         if (it.arity < 2) D1 = 1u;
@@ -860,7 +913,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                                 uint32_t any = 0;
                                 // NQ 128-bit reads (4 rows each) in flight per trip; the wide-block kernels
                                 // (DR = 4: big models, tables in HBM) have the registers for four
-                                constexpr int NQ = DR >= 4 ? 4 : 2;
+                                constexpr int NQ = DR >= 4 ? 4 : (DR == 1 ? 1 : 2);  // DR = 1: one read at a time keeps the kernel at 80 VGPRs (6 wavefronts/SIMD)
                                 for (int c4 = 0; c4 < r1p; c4 += 4 * NQ) {
                                     const uint32_t nib = (D1 >> c4) & ((1u << (4 * NQ)) - 1u);
                                     if (!nib) continue;
@@ -892,13 +945,14 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                                 }
                             }
                         }
-                        if (nev) atomicAdd((unsigned *)&ldom[c.NK], nev);  // statistics: one LDS add, nobody waits for it
+                        S.rows_seen += nev;  // statistics
                         if (s0 == 0) lfail = true;
                         if (s0 != D0) atomicAnd((unsigned *)&ldom[it.idx[0]], s0);
                         if (it.arity > 1 && s1 != D1) atomicAnd((unsigned *)&ldom[it.idx[1]], s1);
                         if (it.arity > 2 && s2 != D2) atomicAnd((unsigned *)&ldom[it.idx[2]], s2);
                         if (it.arity > 3 && s3 != D3) atomicAnd((unsigned *)&ldom[it.idx[3]], s3);
                     }
+#endif
                 }
             }
             dirtyw &= ~smallmask;
@@ -917,12 +971,12 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 if (__ballot(idx < c.NK && nd == 0)) consistent = false;
                 unsigned long long cm = __ballot(nd != dom.r[q]);
                 dom.r[q] = nd;
-                mark_dirty_rows<L>(c, P, S, q, cm, lane, dirtyw);
+                mark_dirty_rows<L>(P, S.rows_abs, S.iw, q, cm, lane, dirtyw);
                 swept_change = swept_change || (cm & pm[q]) != 0;
             }
             need_close = swept_change;  // a word with an eager partner changed
             if (++guard > (1u << 20)) {
-                if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+                S.err = max(S.err, (unsigned)ERR_WATCHDOG);
                 consistent = false;
             }
             ws.cyc_sweep += PHASE_NOW() - t_sw;
@@ -936,30 +990,32 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         int b = __ffs((int)word) - 1;
         int item = wl * 32 + b;
         if (lane == wl) dirtyw &= ~(1u << b);
-        const int ibase = c.o.items + (S.item_begin + item) * (int)(sizeof(ItemDesc) / 4);
-        const int ipoint = P.uc(ibase + 1), icon = P.uc(ibase + 2);
+        // the item record holds the point and the constraint's descriptor: one per-lane read, broadcast by readlane
+        const int ibase = S.items_abs + item * (int)(sizeof(ItemDesc) / 4);
+        const uint32_t irec = lane < (int)(sizeof(ItemDesc) / 4) ? (uint32_t)P.v(ibase + lane) : 0u;
+#define STCSP_ID(f) (int) rdlane(irec, (int)(offsetof(ItemDesc, f) / 4))
+        const int ipoint = STCSP_ID(point);
         ConDesc C;
-        load_con<L>(c, P, icon, C);
+        C.scope_len = STCSP_ID(arity);
+        C.scope_off = STCSP_ID(idx[0]);
+        C.bitmap_off = STCSP_ID(idx[1]);
+        C.stride_off = STCSP_ID(idx[2]);
+        C.n_forbidden = STCSP_ID(idx[3]);
+        C.code_off = STCSP_ID(toff);
+        C.uses_valid = STCSP_ID(r1);
+#undef STCSP_ID
         bool pruned = false;
-        consistent = revise_point<DR, L>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, misc, pm, pruned);
-        need_close = pruned && S.next_off >= 0;
+        consistent = revise_point<DR, L, LITE>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, pruned);
+        need_close = pruned && S.next_abs >= 0;
         ws.cyc_wave += PHASE_NOW() - t_wv;
         if (++guard > (1u << 20)) {
-            if (lane == 0) atomicMax(&misc[MISC_ERROR * CST], (uint32_t)ERR_WATCHDOG);
+            S.err = max(S.err, (unsigned)ERR_WATCHDOG);
             consistent = false;
         }
     }
-    if (lane == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        ws.evals += (unsigned)ldom[c.NK];
-        int *lstat = ldom + c.NK;
-        lstat_add(lstat, ST_NODES, 1);
-        lstat_add(lstat, ST_REVS, ws.revs);
-        lstat_add(lstat, ST_EVALS, (unsigned)ws.evals);
-        lstat_add(lstat, ST_WAVEREVS, ws.wave_revs);
-        lstat_add(lstat, ST_SWEEPS, ws.sweeps);
-        lstat_add(lstat, ST_SKIPPED, ws.skipped);
+    S.n_nodes++;
 #ifdef STCSP_PHASES
+    if (lane == 0) {
         add_stats(c, gw, ST_CYC_SWEEP, ws.cyc_sweep);
         add_stats(c, gw, ST_CYC_WAVE, ws.cyc_wave);
         add_stats(c, gw, ST_CYC_RV_SETUP, ws.cyc_rv_setup);
@@ -969,10 +1025,10 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_RV_BLOCKS, ws.rv_blocks);
         add_stats(c, gw, ST_RV_OPEN, ws.rv_open);
         add_stats(c, gw, ST_RV_LANES, ws.rv_lanes);
-#endif
     }
+#endif
     if (!consistent) {
-        if (lane == 0) lstat_add(ldom + c.NK, ST_FAILS, 1);
+        S.n_fails++;
         return OC_FAIL;
     }
 
@@ -1011,14 +1067,16 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         int fval = (lane < S.nfirst) ? P.v(c.o.var_lb + fv) + __ffs((int)fd) - 1 : 0;
         next_set = -1;
         for (int t = 0; t < S.trans_count && next_set < 0; t++) {
-            int voff = P.u(c.o.trans + (S.trans_begin + t) * 2);
-            bool ne = lane < S.nfirst && P.v(c.o.transvals + voff + lane) != fval;
+            const int voff = P.u(c.o.trans + (S.trans_begin + t) * 2);
+            // every lane reads (no lane-predicated branch inside this loop: see STCSP_REJOIN)
+            const int tv = P.v(c.o.transvals + voff + (lane < S.nfirst ? lane : 0));
+            const bool ne = lane < S.nfirst && tv != fval;
             if (!__ballot(ne)) next_set = P.u(c.o.trans + (S.trans_begin + t) * 2 + 1);
         }
         if (next_set < 0) {
             // unknown transition: park the node again and tell the host which translation is needed
             uint32_t mi = 0;
-            if (lane == 0) mi = atomicAdd(&misc[MISC_NMISS * CST], 1u);
+            if (lane == 0) mi = atomicAdd(&c.ctl[CtlLayout(c.world).misc0 + MISC_NMISS * CST], 1u);
             mi = rflu(mi);
             if ((int)mi < c.miss_cap) {
                 int *rec = c.miss + (size_t)mi * kMissStride;
@@ -1028,7 +1086,8 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 }
                 if (lane < S.nfirst) rec[2 + lane] = fval;
             }
-            if (lane == 0) lstat_add(ldom + c.NK, ST_REQUEUE, 1);
+            STCSP_REJOIN();
+            S.n_requeue++;
             return OC_MISS;
         }
     }
@@ -1080,7 +1139,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         }
         lo.nblk[q] = nb;
     }
-    if (lane == 0) lstat_add(ldom + c.NK, ST_LEAVES, 1);
+    S.n_leaves++;
 #ifdef STCSP_PHASES
     if (lane == 0) add_stats(c, gw, ST_CYC_LEAF, PHASE_NOW() - t_leaf);
 #endif

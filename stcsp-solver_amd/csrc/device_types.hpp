@@ -86,10 +86,11 @@ struct ItemDesc {
     int32_t type;
     int32_t point;
     int32_t con;          // index into cons[] (absolute)
-    int32_t arity;        // IT_SMALL: 1..4 (word variable first)
+    int32_t arity;        // IT_SMALL: 1..4 (word variable first); IT_WAVE: scope length
     int32_t idx[4];       // block word indices p*N+v.  NEXT: idx[0] = (p,X), idx[1] = (p+1,Y)
-    int32_t toff;         // IT_SMALL: into tables[], one 32-bit row per tuple of variables 1..3
-    int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2
+                          // IT_WAVE: the constraint's scope_off, bitmap_off, stride_off, n_forbidden (ConDesc)
+    int32_t toff;         // IT_SMALL: into tables[], one 32-bit row per tuple of variables 1..3; IT_WAVE: code_off
+    int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2; IT_WAVE: r1 = uses_valid
     int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal ; SMALL: number of table rows
 };
 
@@ -183,6 +184,11 @@ STCSP_HD int key_owner(unsigned long long h, int world, int kl, uint32_t tag) {
 STCSP_HD int node_stride(int N, int K) { return (4 + N * K + 3) & ~3; }
 STCSP_HD int cand_stride(int N, int K, int sig_len) { return (kCandHdr + sig_len + N + N * K + 3) & ~3; }
 STCSP_HD int edge_stride(int N) { return (4 + N + 3) & ~3; }
+// transfer record of an open search node (frontier redistribution between shards):
+//   [0,1] src state gid  [2] constraint-set TAG (ordinals differ between shards)  [3] until-expire bits
+//   [4] dirty seed  [5..7] spare  [8..) the N*K-word block
+constexpr int kXferHdr = 8;
+STCSP_HD int xfer_stride(int N, int K) { return (kXferHdr + N * K + 3) & ~3; }
 // candidate record: [0,1] src gid  [2] next set tag  [3] expire bits  [4,5] key hash  [6,7] spare
 //                   [8..) signature, then N edge-label values, then the N*K time-advanced block
 

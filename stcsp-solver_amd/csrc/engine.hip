@@ -40,6 +40,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "cset.hpp"
@@ -103,7 +104,6 @@ struct stcsp_engine {
     // _THRESH / _HEAVY override.
     int chain_small = 4, chain_big = 2, chain_thresh = 4096, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
-    int persist_blocks = 256 * 4;  // k_persist grid: must all be resident
 
     DevBuf<int> d_arr_data, d_code, d_miss;
     DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
@@ -113,17 +113,19 @@ struct stcsp_engine {
     int *h_miss = nullptr;      // pinned
     uint32_t cand_cap = 0;
     DevBuf<Plan> d_plan;
-    DevBuf<uint32_t> d_pq, d_ring, d_seq, d_pstack, d_parked;  // persistent mode
     bool dbg_rounds = false;  // STCSP_DEBUG=2: per-launch log (with STCSP_BURST=1 and STCSP_F_PROFILE)
     std::vector<unsigned long long> dbg_nodes;
     std::vector<long long> dbg_open;
-    bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true>
+    bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true, ..>
+    bool lite = false;            // no constraint needs the general wavefront revision: k_expand<.., .., .., true>
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
+    int64_t step_max_rounds = 0, step_min_open = 0;  // expand_local budget (set_expand_budget): 0 = run the frontier dry
+    DevBuf<uint32_t> d_xfer;                          // donated open nodes (transfer records)
+    std::vector<DevSegment> h_stack;
     std::vector<uint32_t *> pack_ptr;
     std::vector<int64_t> pack_count;
     bool sharded = false;    // candidate / commit pipeline (world > 1 or STCSP_F_STEPPED)
-    bool persist = false;    // STCSP_PERSIST=1: unsharded solves without budgets use k_persist (experimental)
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
     Ctx *h_ctx = nullptr;    // pinned staging copy
     Plan *h_plan = nullptr;  // pinned mirror of the plan header (everything before the stack)
@@ -217,11 +219,17 @@ struct stcsp_engine {
             int w = mgr.ub[v] - mgr.lb[v] + 1;
             init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
         }
-        // Hot sections first (every node reads them; the lane-per-item sweep reads `sweep` and
-        // `itemrows` with per-lane addresses), then the ones only wavefront revisions and leaves of
-        // new sets touch, the (potentially big) tables last. When the whole image does not fit the
-        // LDS budget, a prefix of whole hot sections is staged instead (hot_end[] = candidate cuts).
+        // Sections in the order of how much a node needs them: what every node reads (the lane-per-item sweep
+        // reads `sweep` and `itemrows` with per-lane addresses), then what wavefront revisions read before they can
+        // start (item records, scopes, strides, the bytecode: small, and every read of them sits in a dependent
+        // chain), the ConDesc array (host-side bookkeeping only), the (potentially big) tables last. When the whole
+        // image does not fit the LDS budget, the longest affordable prefix of whole sections is staged instead
+        // (hot_end[] = candidate cuts) and the rest is read from HBM/L2.
         std::vector<int> hot_end;
+        auto cut = [&]() {
+            while (img.size() & 3) img.push_back(0u);
+            hot_end.push_back((int)img.size());
+        };
         o.sets = put(prog.sets.data(), prog.sets.size() * sizeof(SetDesc));
         {
             std::vector<uint32_t> sweep(prog.items.size() * 4);
@@ -237,16 +245,17 @@ struct stcsp_engine {
         o.trans = put(prog.trans.data(), prog.trans.size() * sizeof(TransDesc));
         o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
         o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
-        while (img.size() & 3) img.push_back(0u);
-        hot_end.push_back((int)img.size());
+        cut();
         o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
-        while (img.size() & 3) img.push_back(0u);
-        hot_end.push_back((int)img.size());
+        cut();
         o.hot_words = (int)img.size();
-        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
+        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
         o.scope = put(prog.scope.data(), prog.scope.size() * 4);
         o.strides = put(prog.strides.data(), prog.strides.size() * 4);
-        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
+        cut();
+        o.code = put(prog.code.data(), prog.code.size() * 4);
+        cut();
+        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
         o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
         while (img.size() & 3) img.push_back(0u);
         o.words = (int)img.size();
@@ -259,7 +268,18 @@ struct stcsp_engine {
         compact_sweeps = false;
         for (const SetDesc &sd : prog.sets) compact_sweeps = compact_sweeps || sd.nsmall > kCompactSweepItems;
         ctx.stack_slots = prog.max_stack + 2;
-        const size_t scratch = (size_t)4 * ((kMaxLowVars + ctx.stack_slots) * 64 + ((ctx.NK + kLdsStatWords + 63) & ~63)) * sizeof(int);
+        // LITE: every wavefront-revised constraint is a tuple bitmap with at most one violating tuple. Its
+        // revision then either cannot prune (two or more open variables: the product of the others exceeds the
+        // forbidden set) or is the one-open-variable look-up, so the general enumeration (tuple lanes, odometer,
+        // bytecode interpreter, their LDS scratch and ~25 VGPRs) is compiled out: more resident wavefronts.
+        lite = true;
+        for (const SetDesc &sd : prog.sets)
+            for (int i = sd.nsmall; i < sd.nitems; i++) {
+                const ConDesc &cd = prog.cons[prog.items[sd.item_begin + i].con];
+                lite = lite && cd.bitmap_off >= 0 && cd.n_forbidden >= 0 && cd.n_forbidden <= 1;
+            }
+        if (const char *ev = getenv("STCSP_LITE")) lite = lite && atoi(ev) != 0;  // tuning switch
+        const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
@@ -300,19 +320,8 @@ struct stcsp_engine {
                 max_blocks = per_cu * prop.multiProcessorCount;
             if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
             if (getenv("STCSP_DEBUG"))
-                fprintf(stderr, "[engine] image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
-                        o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
-            // the persistent kernel has its own register footprint
-            switch (DR) {
-                case 1: fn = img_in_lds ? (const void *)k_persist<1, true> : (const void *)k_persist<1, false>; break;
-                case 2: fn = img_in_lds ? (const void *)k_persist<2, true> : (const void *)k_persist<2, false>; break;
-                default: fn = img_in_lds ? (const void *)k_persist<4, true> : (const void *)k_persist<4, false>; break;
-            }
-            per_cu = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
-            if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
-                persist_blocks = per_cu * prop.multiProcessorCount;
-            if (const char *ev = getenv("STCSP_PBLOCKS")) if (atoi(ev) > 0) persist_blocks = atoi(ev);
+                fprintf(stderr, "[engine] %s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
+                        lite ? "LITE" : "general", o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
         }
         return STCSP_OK;
     }
@@ -410,7 +419,6 @@ struct stcsp_engine {
         if (const char *ev = getenv("STCSP_CHAIN_BIG")) chain_big = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_THRESH")) chain_thresh = std::max(0, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_HEAVY")) chain_heavy = std::max(1, atoi(ev));
-        if (const char *ev = getenv("STCSP_PERSIST")) persist = atoi(ev) != 0;
         if (const char *ev = getenv("STCSP_DEBUG")) dbg_rounds = atoi(ev) >= 2;
         sync_ctx();
         return STCSP_OK;
@@ -454,11 +462,6 @@ struct stcsp_engine {
         ctx.plan = d_plan.p;
         ctx.arena = d_arena.p;
         ctx.cand = d_cand.p;
-        ctx.pq = d_pq.p;
-        ctx.ring = d_ring.p;
-        ctx.seq = d_seq.p;
-        ctx.pstack = d_pstack.p;
-        ctx.parked = d_parked.p;
     }
     int flush_ctx() {
         sync_ctx();
@@ -607,35 +610,49 @@ struct stcsp_engine {
         return STCSP_OK;
     }
 
-    // kernel variant: whole image in LDS or not, compacted sweeps (sets with > kCompactSweepItems small items) or not
+    // kernel variant: whole image in LDS or not (L), compacted sweeps (sets with > kCompactSweepItems small
+    // items: CS), no general wavefront revision (LITE)
+    template <int DRT, typename F>
+    void with_variant(F &&f) const {
+        const int v = (img_in_lds ? 4 : 0) | (compact_sweeps ? 2 : 0) | (lite ? 1 : 0);
+        switch (v) {
+            case 0: f(std::integral_constant<int, 0>{}); break;
+            case 1: f(std::integral_constant<int, 1>{}); break;
+            case 2: f(std::integral_constant<int, 2>{}); break;
+            case 3: f(std::integral_constant<int, 3>{}); break;
+            case 4: f(std::integral_constant<int, 4>{}); break;
+            case 5: f(std::integral_constant<int, 5>{}); break;
+            case 6: f(std::integral_constant<int, 6>{}); break;
+            default: f(std::integral_constant<int, 7>{}); break;
+        }
+    }
     template <int DRT>
     const void *expand_fn() const {
-        if (img_in_lds) return compact_sweeps ? (const void *)k_expand<DRT, true, true> : (const void *)k_expand<DRT, true, false>;
-        return compact_sweeps ? (const void *)k_expand<DRT, false, true> : (const void *)k_expand<DRT, false, false>;
+        const void *fn = nullptr;
+        with_variant<DRT>([&](auto v) {
+            constexpr int V = decltype(v)::value;
+            fn = (const void *)k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
+        });
+        return fn;
     }
     template <int DRT>
     void launch_expand() {
         const Ctx *cp = (const Ctx *)d_ctx.p;
-        if (img_in_lds) {
-            if (compact_sweeps) hipLaunchKernelGGL((k_expand<DRT, true, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
-            else hipLaunchKernelGGL((k_expand<DRT, true, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
-        } else {
-            if (compact_sweeps) hipLaunchKernelGGL((k_expand<DRT, false, true>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
-            else hipLaunchKernelGGL((k_expand<DRT, false, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
-        }
+        with_variant<DRT>([&](auto v) {
+            constexpr int V = decltype(v)::value;
+            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+        });
     }
 
     // stcsp_engine_propagate: process_node on caller-provided blocks (k_probe)
     template <int DRT>
     void launch_probe(unsigned grid, uint32_t *blocks, int n, int set, uint32_t expire, int *outcome) {
         const Ctx *cp = (const Ctx *)d_ctx.p;
-        if (img_in_lds) {
-            if (compact_sweeps) hipLaunchKernelGGL((k_probe<DRT, true, true>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
-            else hipLaunchKernelGGL((k_probe<DRT, true, false>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
-        } else {
-            if (compact_sweeps) hipLaunchKernelGGL((k_probe<DRT, false, true>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
-            else hipLaunchKernelGGL((k_probe<DRT, false, false>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set, expire, outcome);
-        }
+        with_variant<DRT>([&](auto v) {
+            constexpr int V = decltype(v)::value;
+            hipLaunchKernelGGL((k_probe<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set,
+                               expire, outcome);
+        });
     }
     int propagate(int set, uint32_t expire, uint32_t *blocks, int64_t count, int32_t *outcome, int64_t *skipped) {
         if (sharded) return fail(STCSP_E_STATE, "propagate is for unsharded engines");
@@ -652,6 +669,7 @@ struct stcsp_engine {
         HIPCHK(d_out.alloc((size_t)count));
         HIPCHK(hipMemcpyAsync(d_blk.p, blocks, words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));  // error / miss words (begin() does the same)
         const unsigned grid = (unsigned)std::min<int64_t>((count + 3) / 4, max_blocks);
         switch (DR) {
             case 1: launch_probe<1>(grid, d_blk.p, (int)count, set, expire, d_out.p); break;
@@ -696,6 +714,7 @@ struct stcsp_engine {
         int rc = replan();
         if (rc != STCSP_OK) return rc;
         const bool prof = opt.flags & STCSP_F_PROFILE;
+        const long long rounds_at_entry = levels;
         for (;;) {
             if ((rc = flush_ctx())) return rc;
             for (int k = 0; k < burst; k++) {
@@ -767,6 +786,9 @@ struct stcsp_engine {
                 truncated = true;
                 return STCSP_OK;
             }
+            // sharded stepping with a budget: hand control back while there is still work to share
+            if (sharded && step_max_rounds > 0 && levels - rounds_at_entry >= step_max_rounds && h_plan->open_total >= step_min_open)
+                return STCSP_OK;
         }
     }
 
@@ -786,93 +808,8 @@ struct stcsp_engine {
         return false;
     }
 
-    template <int DRT>
-    void launch_persist() {
-        if (img_in_lds)
-            hipLaunchKernelGGL((k_persist<DRT, true>), dim3(persist_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
-        else
-            hipLaunchKernelGGL((k_persist<DRT, false>), dim3(persist_blocks), dim3(256), lds_bytes, stream, (const Ctx *)d_ctx.p);
-    }
-    // Persistent mode. Returns 1 when the run has to be redone round-based (a fixed-size pool
-    // overflowed: the round-based path grows pools between launches), 0 on success, < 0 on error.
-    int solve_persistent() {
-        const uint32_t qcap = 1u << 16;
-        const int pstk = 64, park_cap = 4096;
-        const size_t nwaves = (size_t)persist_blocks * 4;
-        if (!d_ring.p) {
-            HIPCHK(d_pq.alloc(PQ_WORDS));
-            HIPCHK(d_ring.alloc((size_t)qcap * ctx.NS));
-            HIPCHK(d_seq.alloc(qcap));
-            HIPCHK(d_parked.alloc((size_t)park_cap * ctx.NS));
-        }
-        if (d_pstack.n < nwaves * pstk * ctx.NS) HIPCHK(d_pstack.alloc(nwaves * pstk * ctx.NS));
-        ctx.qmask = qcap - 1;
-        ctx.pstk_cap = pstk;
-        ctx.park_cap = park_cap;
-        ctx.hungry = (int)nwaves;  // wavefronts in the grid (idle = hungry - active)
-        int rc = begin();  // common initialisation: cursors, statistics, table, root state 0
-        if (rc != STCSP_OK) return rc;
-        std::vector<uint32_t> seqs(qcap);
-        // the ring starts with the root node (written to the arena by begin())
-        std::vector<uint32_t> pending((size_t)ctx.NS);
-        HIPCHK(hipMemcpy(pending.data(), d_arena.p, (size_t)ctx.NS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        size_t n_pending = 1;
-        for (;;) {
-            // (re)load the ring with the pending nodes: slots [0, n) full, the rest empty
-            for (uint32_t i = 0; i < qcap; i++) seqs[i] = i < n_pending ? i + 1 : i;
-            std::vector<uint32_t> pq(PQ_WORDS, 0u);
-            pq[PQ_TAIL] = (uint32_t)n_pending;
-            pq[PQ_PENDING] = (uint32_t)n_pending;
-            HIPCHK(hipMemcpyAsync(d_seq.p, seqs.data(), qcap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_pq.p, pq.data(), PQ_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_ring.p, pending.data(), n_pending * ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            if ((rc = flush_ctx())) return rc;
-            HIPCHK(hipStreamSynchronize(stream));  // staging vectors are pageable
-            const bool prof = opt.flags & STCSP_F_PROFILE;
-            if (prof) {
-                if (ev_used == ev_pool.size()) {
-                    hipEvent_t e0, e1;
-                    HIPCHK(hipEventCreate(&e0));
-                    HIPCHK(hipEventCreate(&e1));
-                    ev_pool.emplace_back(e0, e1);
-                }
-                HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
-            }
-            switch (DR) {
-                case 1: launch_persist<1>(); break;
-                case 2: launch_persist<2>(); break;
-                default: launch_persist<4>(); break;
-            }
-            HIPCHK(hipGetLastError());
-            if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
-            expand_launches++;
-            levels++;
-            HIPCHK(hipMemcpyAsync(pq.data(), d_pq.p, PQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            const uint32_t dev_err = h_ctl[L.misc0 + MISC_ERROR * CST], ab = pq[PQ_ABORT];
-            if (dev_err == ERR_EDGE_OVERFLOW || dev_err == ERR_STATE_OVERFLOW || ab == AB_QUEUE_FULL || ab == AB_PARK_FULL)
-                return 1;  // fixed-size pool too small for this instance: redo with growing pools
-            if (dev_err || ab) return fail(STCSP_E_INTERNAL, "persistent kernel stopped: device error %u, abort %u", dev_err, ab);
-            n_pending = pq[PQ_PARKED];
-            if (n_pending == 0) break;
-            // leaves waiting for a constraint-set translation: translate, then run them again
-            if ((rc = service_misses())) return rc;
-            pending.resize(n_pending * ctx.NS);
-            HIPCHK(hipMemcpy(pending.data(), d_parked.p, pending.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
-        return 0;
-    }
-
     int solve_unsharded() {
-        int rc;
-        if (persist && opt.time_limit_s <= 0 && opt.max_search_nodes <= 0) {
-            rc = solve_persistent();
-            if (rc < 0) return rc;
-            if (rc == 0) return finish();
-            // fall through: redo round-based
-        }
-        rc = begin();
+        int rc = begin();
         if (rc != STCSP_OK) return rc;
         rc = run_rounds();
         if (rc != STCSP_OK) return rc;
@@ -895,10 +832,6 @@ struct stcsp_engine {
         ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
         ctr.sweeps = (int64_t)tot[ST_SWEEPS];
         ctr.skipped_revisions = (int64_t)tot[ST_SKIPPED];
-        if (getenv("STCSP_DEBUG") && tot[ST_POLLS])
-            fprintf(stderr, "[persist] pushes %llu pops %llu private pops %llu polls %llu waves that worked %llu; idle Mcycles %.1f busy Mcycles %.1f\n",
-                    (unsigned long long)tot[ST_QPUSH], (unsigned long long)tot[ST_QPOP], (unsigned long long)tot[ST_PSTACK_POP],
-                    (unsigned long long)tot[ST_POLLS], (unsigned long long)tot[ST_WAVES_WORKED], tot[ST_IDLE_CYC] / 1e6, tot[ST_BUSY_CYC] / 1e6);
 #ifdef STCSP_PHASES
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: node load %.0f | process_node %.0f (of which sweeps %.0f, wavefront revisions %.0f) | emit/commit %.0f | total %.0f (nodes %llu)\n",
@@ -1046,6 +979,71 @@ struct stcsp_engine {
         // which is also where an overflow reported by k_commit surfaces. `records` must stay valid
         // until then (the driver keeps its receive buffer for the whole superstep).
         return STCSP_OK;
+    }
+
+    // ---- frontier redistribution (stcsp_engine.h): the oldest open nodes leave / received ones join
+    int donate(int64_t want, void **ptr, int64_t *count) {
+        if (!begun || !sharded) return fail(STCSP_E_STATE, "donate is part of the sharded stepping interface (after begin)");
+        *ptr = nullptr;
+        *count = 0;
+        if (want <= 0) return STCSP_OK;
+        int rc = STCSP_OK;
+        if (!host_view_fresh && ((rc = read_ctl()) || (rc = read_plan()))) return rc;
+        const int sp = h_plan->sp;
+        if (sp <= 0) return STCSP_OK;
+        h_stack.resize((size_t)sp);
+        HIPCHK(hipMemcpy(h_stack.data(), &d_plan.p->stack[0], (size_t)sp * sizeof(DevSegment), hipMemcpyDeviceToHost));
+        const int TS = xfer_stride(ctx.N, ctx.K);
+        if (d_xfer.n < (size_t)want * TS) HIPCHK(d_xfer.alloc((size_t)want * TS));
+        if ((rc = flush_ctx())) return rc;
+        int64_t done = 0;
+        for (int sg = 0; sg < sp && done < want; sg++) {  // bottom of the stack first: the shallowest nodes
+            DonateArgs a{};
+            a.seg_base = h_stack[sg].base;
+            a.seg_cap = h_stack[sg].cap;
+            a.seg = sg;
+            int64_t avail = 0;
+            for (int r = 0; r < R; r++) avail += (a.count[r] = h_stack[sg].count[r]);
+            if (!avail) continue;
+            int64_t need = std::min<int64_t>(want - done, avail);
+            const int64_t share = need / R;
+            for (int r = 0; r < R; r++) need -= (a.take[r] = (int)std::min<int64_t>(a.count[r], share));
+            for (int r = 0; r < R && need > 0; r++) {  // what the even shares left over
+                const int extra = (int)std::min<int64_t>(a.count[r] - a.take[r], need);
+                a.take[r] += extra;
+                need -= extra;
+            }
+            uint32_t acc = 0;
+            for (int r = 0; r < R; r++) {
+                a.pref[r] = acc;
+                acc += (uint32_t)a.take[r];
+            }
+            a.pref[R] = acc;
+            hipLaunchKernelGGL(k_donate, dim3((acc + 3) / 4), dim3(256), 0, stream, ctx, a, d_xfer.p + (size_t)done * TS);
+            HIPCHK(hipGetLastError());
+            done += acc;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        h_plan->open_total -= done;
+        *ptr = d_xfer.p;
+        *count = done;
+        return STCSP_OK;
+    }
+    int adopt(const void *records, int64_t count) {
+        if (!begun || !sharded) return fail(STCSP_E_STATE, "adopt is part of the sharded stepping interface (after begin)");
+        if (count <= 0) return STCSP_OK;
+        int rc = STCSP_OK;
+        if (!host_view_fresh && ((rc = read_ctl()) || (rc = read_plan()))) return rc;  // (waits for a commit in flight)
+        host_view_fresh = false;
+        const unsigned cap = (unsigned)((count + R - 1) / R + 1);
+        if ((size_t)h_plan->arena_top + (size_t)R * cap * ctx.NS > d_arena.n)
+            if ((rc = grow_arena((size_t)h_plan->arena_top + (size_t)R * cap * ctx.NS))) return rc;
+        if ((rc = push_caps())) return rc;
+        hipLaunchKernelGGL(k_open_segment, dim3(1), dim3(64), 0, stream, ctx, cap);
+        hipLaunchKernelGGL(k_adopt, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, ctx, (const uint32_t *)records, (long long)count);
+        hipLaunchKernelGGL(k_close_segment, dim3(1), dim3(64), 0, stream, ctx);
+        HIPCHK(hipGetLastError());
+        return STCSP_OK;  // not waited for (like commit): `records` must stay valid until the next expand_local / finish
     }
 
     // graphTraverse / adversarialTraverse / adversarialTraverse2 on the device (dev_postproc.hpp)
@@ -1441,6 +1439,18 @@ int stcsp_engine_outbox(stcsp_engine *e, int peer, void **ptr, int64_t *count) {
 }
 int stcsp_engine_commit(stcsp_engine *e, const void *records, int64_t count) { return e ? e->commit(records, count) : STCSP_E_INVALID; }
 int stcsp_engine_finish(stcsp_engine *e) { return e ? e->finish() : STCSP_E_INVALID; }
+int stcsp_engine_set_expand_budget(stcsp_engine *e, int64_t max_rounds, int64_t min_open) {
+    if (!e || max_rounds < 0 || min_open < 0) return STCSP_E_INVALID;
+    e->step_max_rounds = max_rounds;
+    e->step_min_open = min_open;
+    return STCSP_OK;
+}
+int stcsp_engine_node_bytes(const stcsp_engine *e) { return e ? xfer_stride(e->ctx.N, e->ctx.K) * 4 : STCSP_E_INVALID; }
+int stcsp_engine_donate(stcsp_engine *e, int64_t want, void **ptr, int64_t *count) {
+    if (!e || !ptr || !count) return STCSP_E_INVALID;
+    return e->donate(want, ptr, count);
+}
+int stcsp_engine_adopt(stcsp_engine *e, const void *records, int64_t count) { return e ? e->adopt(records, count) : STCSP_E_INVALID; }
 int stcsp_engine_counters(stcsp_engine *e, stcsp_counters *out) {
     if (!e || !out) return STCSP_E_INVALID;
     if (!e->begun) return e->fail(STCSP_E_STATE, "counters before a solve");

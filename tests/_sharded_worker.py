@@ -21,6 +21,10 @@ def load_model(st, spec, prefix_k=2):
 
 
 def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
+    # redistribution knobs for the tests (small instances must share early to exercise the path)
+    budget = dict(budget_rounds=int(os.environ.get("STCSP_TEST_BUDGET_ROUNDS", "8")),
+                  share_per_rank=int(os.environ.get("STCSP_TEST_SHARE", "64")))
+    stats = {}
     import torch
     import torch.distributed as dist
 
@@ -47,7 +51,7 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
 
         eng = FModel(m, rank=rank, world=world)
         device = torch.device("cpu")
-        rounds = sh.solve_sharded(eng, rank, world, device)
+        rounds = sh.solve_sharded(eng, rank, world, device, stats=stats, **budget)
     elif backend_kind == "hip-nccl":
         # the production N>1 code path on one GPU: RCCL process group of size 1, candidates stay in
         # HBM (all_to_all_single on views of the engine's outbox), STCSP_F_STEPPED forces the
@@ -66,14 +70,22 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         # the real HIP engine, every shard on GPU 0, all-to-all staged through host (gloo)
         eng = st.Engine(m, device=0, rank=rank, world=world)
         device = torch.device("cuda:0")
-        rounds = sh.solve_sharded(eng, rank, world, device, stage_through_host=True)
-    merged = sh.gather_and_merge(st, eng, rank, world)
+        rounds = sh.solve_sharded(eng, rank, world, device, stage_through_host=True, stats=stats, **budget)
+    # every rank's own search-node count (tensor collective)
+    mine = torch.tensor([eng.counters().search_nodes, stats.get("nodes_donated", 0), stats.get("nodes_adopted", 0)], dtype=torch.int64)
+    everyone = torch.empty(3 * world, dtype=torch.int64)
+    if backend_kind == "hip-nccl":
+        mine, everyone = mine.cuda(), everyone.cuda()
+    dist.all_gather_into_tensor(everyone, mine)
+    everyone = everyone.cpu().view(world, 3).tolist()
+    merged = sh.gather_and_merge(st, eng, rank, world, device)
     if rank == 0:
         h, res = merged
         a = st.Automaton(m, res).traverse().renumber()
         out = dict(states=a.n_live_states, edges=a.n_live_edges, sha=a.canonical_sha256(), rounds=rounds,
                    table=res.n_states, dom=res.counters.dominance, nodes=res.counters.search_nodes,
-                   sets=res.n_constraint_sets, fails=res.counters.fails, canonical=a.canonical() if a.n_states <= 4096 else None)
+                   sets=res.n_constraint_sets, fails=res.counters.fails, rank_nodes=[e[0] for e in everyone],
+                   donated=[e[1] for e in everyone], adopted=[e[2] for e in everyone], canonical=a.canonical() if a.n_states <= 4096 else None)
         if backend_kind == "hip-nccl":
             out["stepped_ms"] = stepped_ms
         Path(out_path).write_text(json.dumps(out))

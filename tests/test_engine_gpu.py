@@ -155,21 +155,6 @@ def test_engine_pool_growth_paths(stcsp, golden, monkeypatch):
         assert r.n_states == golden[name]["node"] or golden[name]["fail"] > 0
 
 
-def test_engine_persistent_mode_parity(stcsp, golden, monkeypatch):
-    """The experimental persistent work-queue kernel (STCSP_PERSIST=1: private DFS stacks + a
-    shared MPMC ring, no rounds) must produce the same automaton, including the relaunch after a
-    constraint-set translation miss."""
-    monkeypatch.setenv("STCSP_PERSIST", "1")
-    monkeypatch.setenv("STCSP_PBLOCKS", "64")   # few wavefronts: see the status note in engine.hip
-    for name in ["juggling_b4_f5", "juggling_b4_f4_nosym", "digitinvader2", "partialorder_10"]:
-        m = stcsp.Model.from_name(name)
-        e = stcsp.Engine(m)
-        r = e.solve()
-        a, _ = finish(e, r)
-        assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
-        assert r.counters.levels <= 3  # launches: 1 + one per translation round
-
-
 def test_engine_array_validity_semantics(stcsp, RefOracle):
     """Out-of-range array lookups (reference `valid` flag), also under branches that are not
     taken: tabulated by the host evaluator and checked against the oracle."""

@@ -1,8 +1,8 @@
 """Diagnostic: per-phase cycle shares of k_expand (needs csrc/libstcsp_hip_phases.so, built with -DSTCSP_PHASES)."""
-import ctypes as C, importlib, sys
+import ctypes as C, importlib, os, sys
 sys.path.insert(0, '.')
 st = importlib.import_module("stcsp-solver_amd")
-lib = C.CDLL(str(st.CSRC / "libstcsp_hip_phases.so")); st.bind_engine_api(lib)
+lib = C.CDLL(str(st.CSRC / os.environ.get("STCSP_PHASES_LIB", "libstcsp_hip_phases.so"))); st.bind_engine_api(lib)
 class E(st.EngineBase):
     def __init__(self, m, **o): super().__init__(lib, m, **o)
 for name in sys.argv[1:] or ["partialorder_14"]:
