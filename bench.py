@@ -42,11 +42,13 @@ SYNTH = (64, 32, 602, 6, 20261003)  # BASELINE config 4: 64 vars x |D| = 32, 602
 REFERENCE_P14_NODES_PER_S = 10.9e3  # the reference itself, survey VM, 1 core
 
 
-def cpu_baseline(st, name, seconds):
-    """Time-boxed run of the reference-faithful CPU restatement (kind = "port")."""
+def cpu_baseline(st, name, seconds, threads):
+    """Time-boxed runs of the reference-faithful CPU restatement (kind = "port"): one thread (the reference is
+    single-threaded), and `threads` workers over the automaton's states (oracle/ref_dfs.cpp struct Shared)."""
     path = REPO / "oracle" / "libstcsp_oracle.so"
     lib = C.CDLL(str(path))
     st.bind_engine_api(lib, "stcsp_oracle")
+    lib.stcsp_oracle_solve_parallel.argtypes = [C.c_void_p, C.c_int, C.POINTER(st.Result)]
 
     class Ref(st.EngineBase):
         _prefix = "stcsp_oracle"
@@ -60,12 +62,23 @@ def cpu_baseline(st, name, seconds):
     r = o.solve()
     wall = time.time() - t0
     nodes = r.counters.search_nodes
-    return {"value": nodes / wall, "unit": "search-tree nodes/s", "cores": 1, "kind": "port",
-            "sample": f"first {wall:.1f} s of the DFS on {name} ({nodes} nodes, "
-                      f"{'truncated' if r.truncated else 'complete'}); oracle/ref_dfs.cpp, 1 thread. The reference itself "
-                      f"(unbuildable on this box) measured {REFERENCE_P14_NODES_PER_S:.0f} nodes/s on partialorder_14 on the "
-                      "survey VM (1 core; it leaks 16 kB per leaf, half of its time is page faults)",
-            "host_cpus": os.cpu_count()}
+    out = {"value": nodes / wall, "unit": "search-tree nodes/s", "cores": 1, "kind": "port",
+           "sample": f"first {wall:.1f} s of the DFS on {name} ({nodes} nodes, "
+                     f"{'truncated' if r.truncated else 'complete'}); oracle/ref_dfs.cpp, 1 thread. The reference itself "
+                     f"(unbuildable on this box) measured {REFERENCE_P14_NODES_PER_S:.0f} nodes/s on partialorder_14 on the "
+                     "survey VM (1 core; it leaks 16 kB per leaf, half of its time is page faults)",
+           "host_cpus": os.cpu_count()}
+    if threads > 1:
+        op = Ref(m, time_limit_s=seconds)
+        t0 = time.time()
+        op._check(lib.stcsp_oracle_solve_parallel(op._h, threads, C.byref(op.result)))
+        wall = time.time() - t0
+        rp = op.result
+        out["all_cores"] = {"value": rp.counters.search_nodes / wall, "unit": "search-tree nodes/s", "cores": threads, "kind": "port",
+                            "sample": f"{wall:.1f} s on {name} ({rp.counters.search_nodes} nodes, {'truncated' if rp.truncated else 'complete'}): "
+                                      f"the same restatement with {threads} workers over the automaton's states (shared state table, "
+                                      "ok/fail by fixpoint)"}
+    return out
 
 
 def alg_bytes(model, res_sig_len, nodes, leaves):
@@ -135,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU leg (default: min(host cpus, 16), the box's CPU share)")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--synthetic-seconds", type=float, default=2.0)
     ap.add_argument("--stepped", action="store_true",
@@ -223,7 +237,7 @@ def main():
         check = {"states": a.n_live_states, "edges": a.n_live_edges, "canonical_sha256": a.canonical_sha256()}
     else:
         try:  # gather the shards, merge, canonical hash
-            merged = sh.gather_and_merge(st, eng, rank, world)
+            merged = sh.gather_and_merge(st, eng, rank, world, dev)
             if rank == 0:
                 _, mres = merged
                 a = st.Automaton(model, mres).traverse().renumber()
@@ -297,7 +311,7 @@ def main():
             "parity": check,
         }
         if not args.no_cpu_baseline and world == 1 and not args.stepped:
-            out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds, args.cpu_threads or min(os.cpu_count() or 1, 16))
         print(json.dumps(out), flush=True)
     if stepped:
         ok = torch.tensor([1 if parity_ok else 0], dtype=torch.int64, device=dev)

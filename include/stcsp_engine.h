@@ -134,6 +134,8 @@ typedef struct stcsp_counters {
     int64_t sweeps;         /* engine only: lane-per-item sweeps over the small constraints         */
     int64_t skipped_revisions; /* engine only: revisions skipped because the product to refute
                                   exceeded the per-revision budget (sound, see engine.hip)          */
+    int64_t translation_stops; /* engine only: times the device stopped for the host to translate a
+                                  constraint set (constraintTranslate, constraint.cpp:540-548)       */
 } stcsp_counters;
 
 /* The automaton as the search leaves it in solver->graph, before graphTraverse.

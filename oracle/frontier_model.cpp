@@ -400,7 +400,7 @@ struct Model {
     // expand_local returns early once it has expanded budget_rounds * kRoundNodes nodes and holds >= budget_min_open
     // open nodes (the engine's launch rounds have no counterpart here; a "round" stands for kRoundNodes expansions)
     int64_t budget_rounds = 0, budget_min_open = 0;
-    static constexpr int64_t kRoundNodes = 64;
+    static constexpr int64_t kRoundNodes = 8;
     int expand_local(int64_t *left) {
         int64_t done = 0;
         while (!open.empty()) {

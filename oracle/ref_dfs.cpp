@@ -23,11 +23,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
 
+#include "../stcsp-solver_amd/csrc/okfix.hpp"
 #include "stcsp_engine.h"
 
 namespace {
@@ -69,7 +73,33 @@ struct State {  // graph.h:47-56
     bool fail = false;
 };
 
+// ---- CPU baseline on all host cores (SURVEY 8(d) baseline (ii), bench.py only): the reference's algorithm
+// with the automaton's STATES as the unit of parallel work. Every worker is a complete Oracle (its own
+// domains, trail, arc queue and constraint-set copies: Arc::inqueue is mutable); they share the state table and
+// a task queue. A leaf that opens a new state does not recurse into it (solveralgorithm.cpp:857) but queues it,
+// with the time-advanced window, for any worker; every leaf edge is logged and the ok/fail bookkeeping
+// (:865-909), which depends on the depth-first order, is replaced by the order-independent fixpoint the engine
+// uses (okfix.hpp). Same automaton; the tree can differ slightly (which parent opens a state is a race).
+struct Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<std::vector<int32_t>, int> gsets;      // serialised set content -> global set id
+    std::vector<std::vector<int32_t>> gset_words;   // global set id -> content
+    std::map<std::pair<int, std::vector<int>>, int> table;
+    std::vector<State> states;
+    struct Task {
+        int vertex, gcid;
+        std::vector<int> lb, ub, expire;
+    };
+    std::deque<Task> queue;
+    int active = 0;
+    std::atomic<bool> stop{false};
+};
+
 struct Oracle {
+    Shared *sh = nullptr;            // non-null: worker of a parallel run
+    std::vector<int> g_of_local;     // this worker's seen[] index -> global set id (-1: not asked yet)
+    std::map<int, int> local_of_g;
     // model
     int N = 0, K = 2;
     std::vector<int> lb, ub;
@@ -317,6 +347,75 @@ struct Oracle {
         return true;
     }
 
+    // ---- parallel runs: a constraint set travels between workers as its serialised trees
+    static void ser_tree(const Expr *e, std::vector<int32_t> &out) {
+        if (!e) {
+            out.push_back(INT32_MIN);
+            return;
+        }
+        out.push_back(e->token);
+        out.push_back(e->num);
+        out.push_back(e->var);
+        out.push_back(e->arr);
+        ser_tree(e->left, out);
+        ser_tree(e->right, out);
+    }
+    static std::vector<int32_t> ser_set(const ConSet &s) {
+        std::vector<int32_t> out;
+        for (auto &c : s.cons) ser_tree(c->root, out);
+        return out;
+    }
+    Expr *deser_tree(ConSet &s, const std::vector<int32_t> &w, size_t &pos) {
+        if (w[pos] == INT32_MIN) {
+            pos++;
+            return nullptr;
+        }
+        int token = w[pos], num = w[pos + 1], var = w[pos + 2], arr = w[pos + 3];
+        pos += 4;
+        Expr *l = deser_tree(s, w, pos);
+        Expr *r = deser_tree(s, w, pos);
+        return mk(s, token, num, var, arr, l, r);
+    }
+    // global id of this worker's set `local` (registering its content when nobody has met it yet)
+    int global_set(int local) {
+        if ((int)g_of_local.size() <= local) g_of_local.resize(local + 1, -1);
+        if (g_of_local[local] >= 0) return g_of_local[local];
+        std::vector<int32_t> words = ser_set(*seen[local]);
+        std::lock_guard<std::mutex> lk(sh->mu);
+        auto it = sh->gsets.find(words);
+        int g;
+        if (it == sh->gsets.end()) {
+            g = (int)sh->gset_words.size();
+            sh->gsets.emplace(words, g);
+            sh->gset_words.push_back(words);
+        } else {
+            g = it->second;
+        }
+        g_of_local[local] = g;
+        local_of_g[g] = local;
+        return g;
+    }
+    // this worker's copy of global set g (built from the registry when another worker discovered it)
+    int local_set(int g) {
+        auto it = local_of_g.find(g);
+        if (it != local_of_g.end()) return it->second;
+        std::vector<int32_t> words;
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            words = sh->gset_words[g];
+        }
+        std::unique_ptr<ConSet> ns(new ConSet());
+        ns->var_cons.resize(N);
+        size_t pos = 0;
+        while (pos < words.size()) push_constraint(*ns, deser_tree(*ns, words, pos));
+        int local = (int)seen.size();
+        seen.push_back(std::move(ns));
+        if ((int)g_of_local.size() <= local) g_of_local.resize(local + 1, -1);
+        g_of_local[local] = g;
+        local_of_g[g] = local;
+        return local;
+    }
+
     // ---- expression evaluation, solverValidateRe (solveralgorithm.cpp:336-424)
     int eval(const Expr *e, bool &valid) {
         if (!e) return 0;
@@ -495,12 +594,14 @@ struct Oracle {
     }
 
     bool over_budget() {
+        if (sh && sh->stop.load(std::memory_order_relaxed)) stop = true;
         if (stop) return true;
         if (max_nodes && ctr.search_nodes >= max_nodes) stop = true;
         if (time_limit > 0 && (ctr.search_nodes & 1023) == 0) {
             double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (s > time_limit) stop = true;
         }
+        if (stop && sh) sh->stop.store(true, std::memory_order_relaxed);
         return stop;
     }
 
@@ -557,6 +658,54 @@ struct Oracle {
                         sig.push_back(0);
                     }
                 }
+            if (sh) {
+                // parallel run: look the state up in the shared table; a new state becomes a task
+                const int g = global_set(cid);
+                auto key = std::make_pair(g, sig);
+                int dst;
+                bool is_new = false;
+                {
+                    std::lock_guard<std::mutex> lk(sh->mu);
+                    auto it = sh->table.find(key);
+                    if (it == sh->table.end()) {
+                        dst = (int)sh->states.size();
+                        sh->states.push_back(State{g, sig, false});
+                        sh->table.emplace(key, dst);
+                        is_new = true;
+                    } else {
+                        dst = it->second;
+                    }
+                }
+                if (is_new) {
+                    Shared::Task t;
+                    t.vertex = dst;
+                    t.gcid = g;
+                    t.lb.resize((size_t)N * K);
+                    t.ub.resize((size_t)N * K);
+                    for (int v = 0; v < N; v++) {  // variableAdvanceOneTimeStep (variable.cpp:94-108)
+                        for (int p = 0; p < K - 1; p++) {
+                            t.lb[v * K + p] = LB(v, p + 1);
+                            t.ub[v * K + p] = UB(v, p + 1);
+                        }
+                        t.lb[v * K + K - 1] = lb[v];
+                        t.ub[v * K + K - 1] = ub[v];
+                    }
+                    t.expire = expire;
+                    {
+                        std::lock_guard<std::mutex> lk(sh->mu);
+                        sh->queue.push_back(std::move(t));
+                    }
+                    sh->cv.notify_one();
+                } else {
+                    ctr.dominance++;
+                }
+                cur = saved;
+                e_src.push_back(vertex);  // every leaf edge is logged (this worker's log); okfix decides later
+                e_dst.push_back(dst);
+                for (int v = 0; v < N; v++) e_val.push_back(LB(v, 0));
+                level_down();
+                return !stop;
+            }
             auto key = std::make_pair(cid, sig);
             auto it = table.find(key);
             int dst;
@@ -670,6 +819,46 @@ struct Oracle {
         ctr.seconds_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 
+    // worker of a parallel run: take states from the shared queue until none is left and nobody is working
+    void work() {
+        t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            Shared::Task t;
+            {
+                std::unique_lock<std::mutex> lk(sh->mu);
+                sh->cv.wait(lk, [&] { return !sh->queue.empty() || sh->active == 0 || sh->stop.load(); });
+                if (sh->stop.load() || (sh->queue.empty() && sh->active == 0)) {
+                    sh->cv.notify_all();
+                    return;
+                }
+                if (sh->queue.empty()) continue;
+                t = std::move(sh->queue.front());
+                sh->queue.pop_front();
+                sh->active++;
+            }
+            // install the state: its constraint set, the time-advanced window, the until flags
+            const int local = local_set(t.gcid);
+            cur = seen[local].get();
+            cid = local;
+            curLB = t.lb;
+            curUB = t.ub;
+            expire = t.expire;
+            trail.clear();
+            level_up();
+            if (gac()) {
+                search(t.vertex);
+            } else {
+                ctr.fails++;
+            }
+            level_down();
+            {
+                std::lock_guard<std::mutex> lk(sh->mu);
+                sh->active--;
+            }
+            sh->cv.notify_all();
+        }
+    }
+
     void fill(stcsp_result *r) {
         memset(r, 0, sizeof *r);
         int sl = num_sig + n_until_cons;
@@ -710,11 +899,23 @@ void *thread_main(void *p) {
     static_cast<ThreadArg *>(p)->o->run();
     return nullptr;
 }
+void *worker_main(void *p) {
+    static_cast<ThreadArg *>(p)->o->work();
+    return nullptr;
+}
 
 }  // namespace
 
 struct stcsp_oracle {
     Oracle o;
+    // parallel runs
+    const stcsp_problem *problem = nullptr;
+    stcsp_options options{};
+    Shared shared;
+    std::vector<std::unique_ptr<Oracle>> workers;
+    std::vector<int32_t> p_cid, p_sig, p_val;
+    std::vector<uint8_t> p_fail, p_issig;
+    std::vector<int64_t> p_src, p_dst;
 };
 
 extern "C" {
@@ -724,7 +925,123 @@ int stcsp_oracle_create(const stcsp_problem *problem, const stcsp_options *optio
     std::unique_ptr<stcsp_oracle> h(new stcsp_oracle());
     int rc = h->o.setup(problem, options);
     if (rc != STCSP_OK) return rc;
+    h->problem = problem;  // (the caller keeps the problem alive as long as the oracle: bench.py / tests do)
+    if (options) h->options = *options;
     *out = h.release();
+    return STCSP_OK;
+}
+
+// The reference's algorithm on `threads` host cores (see struct Shared). Same result layout as solve().
+int stcsp_oracle_solve_parallel(stcsp_oracle *h, int threads, stcsp_result *result) {
+    if (!h || !result || threads < 1 || !h->problem) return STCSP_E_INVALID;
+    Shared &sh = h->shared;
+    sh.table.clear();
+    sh.states.clear();
+    sh.queue.clear();
+    sh.gsets.clear();
+    sh.gset_words.clear();
+    sh.active = 0;
+    sh.stop = false;
+    h->workers.clear();
+    for (int t = 0; t < threads; t++) {
+        h->workers.emplace_back(new Oracle());
+        Oracle &w = *h->workers.back();
+        int rc = w.setup(h->problem, &h->options);
+        if (rc != STCSP_OK) return rc;
+        w.sh = &sh;
+    }
+    Oracle &w0 = *h->workers[0];
+    w0.global_set(0);  // the model's own set is global set 0 (identical in every clone)
+    for (auto &w : h->workers) {
+        w->g_of_local.assign(1, 0);
+        w->local_of_g[0] = 0;
+    }
+    // root: Signature({}, 0) with the initial domains (solveralgorithm.cpp:951-968)
+    sh.states.push_back(State{0, {}, false});
+    sh.table.emplace(std::make_pair(0, std::vector<int>()), 0);
+    Shared::Task root;
+    root.vertex = 0;
+    root.gcid = 0;
+    root.lb = w0.curLB;
+    root.ub = w0.curUB;
+    root.expire = w0.expire;
+    sh.queue.push_back(std::move(root));
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<pthread_t> th(threads);
+    std::vector<ThreadArg> args(threads);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, (size_t)256 << 20);
+    for (int t = 0; t < threads; t++) {
+        args[t].o = h->workers[t].get();
+        if (pthread_create(&th[t], &attr, worker_main, &args[t]) != 0) return STCSP_E_NOMEM;
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], nullptr);
+    pthread_attr_destroy(&attr);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // merge the workers' edge logs, then the order-independent ok/fail fixpoint
+    const int N = w0.N;
+    h->p_src.clear();
+    h->p_dst.clear();
+    h->p_val.clear();
+    stcsp_counters ctr{};
+    for (auto &w : h->workers) {
+        h->p_src.insert(h->p_src.end(), w->e_src.begin(), w->e_src.end());
+        h->p_dst.insert(h->p_dst.end(), w->e_dst.begin(), w->e_dst.end());
+        h->p_val.insert(h->p_val.end(), w->e_val.begin(), w->e_val.end());
+        ctr.search_nodes += w->ctr.search_nodes;
+        ctr.gac_calls += w->ctr.gac_calls;
+        ctr.fails += w->ctr.fails;
+        ctr.leaves += w->ctr.leaves;
+        ctr.revisions += w->ctr.revisions;
+        ctr.evaluations += w->ctr.evaluations;
+    }
+    const int64_t ns = (int64_t)sh.states.size();
+    h->p_fail.assign((size_t)ns, 0);
+    std::vector<uint8_t> alive;
+    stcsp::ok_fixpoint(ns, h->p_src, h->p_dst, h->p_fail, alive);
+    size_t wq = 0;
+    for (size_t e = 0; e < alive.size(); e++)
+        if (alive[e]) {
+            h->p_src[wq] = h->p_src[e];
+            h->p_dst[wq] = h->p_dst[e];
+            if (wq != e) memmove(&h->p_val[wq * N], &h->p_val[e * N], (size_t)N * 4);
+            wq++;
+        }
+    h->p_src.resize(wq);
+    h->p_dst.resize(wq);
+    h->p_val.resize(wq * N);
+    const int sl = w0.num_sig + w0.n_until_cons;
+    h->p_cid.resize((size_t)ns);
+    h->p_sig.assign((size_t)ns * sl, 0);
+    int64_t ok_states = 0;
+    for (int64_t i = 0; i < ns; i++) {
+        h->p_cid[i] = sh.states[i].cid;
+        for (size_t j = 0; j < sh.states[i].sig.size() && j < (size_t)sl; j++) h->p_sig[i * sl + j] = sh.states[i].sig[j];
+        if (i) ok_states += !h->p_fail[i];
+    }
+    ctr.dominance = (int64_t)wq - ok_states;
+    ctr.seconds_search = secs;
+    h->p_issig.assign(w0.is_sig.begin(), w0.is_sig.end());
+    memset(result, 0, sizeof *result);
+    result->n_states = ns;
+    result->sig_len = sl;
+    result->n_sig_vars = w0.num_sig;
+    result->n_until = w0.num_until;
+    result->n_until_cons = w0.n_until_cons;
+    result->state_cid = h->p_cid.data();
+    result->state_sig = h->p_sig.data();
+    result->state_fail = h->p_fail.data();
+    result->n_edges = (int64_t)wq;
+    result->edge_src = h->p_src.data();
+    result->edge_dst = h->p_dst.data();
+    result->edge_values = h->p_val.data();
+    result->n_vars = N;
+    result->n_constraint_sets = (int32_t)sh.gset_words.size();
+    result->var_is_signature = h->p_issig.data();
+    result->root_final = w0.n_until_cons == 0;
+    result->truncated = sh.stop.load();
+    result->counters = ctr;
     return STCSP_OK;
 }
 

@@ -51,7 +51,8 @@ class Counters(C.Structure):
                 ("evaluations", C.c_int64), ("levels", C.c_int64),
                 ("seconds_search", C.c_double), ("seconds_export", C.c_double),
                 ("seconds_expand_kernel", C.c_double), ("expand_launches", C.c_int64),
-                ("wave_revisions", C.c_int64), ("sweeps", C.c_int64), ("skipped_revisions", C.c_int64)]
+                ("wave_revisions", C.c_int64), ("sweeps", C.c_int64), ("skipped_revisions", C.c_int64),
+                ("translation_stops", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

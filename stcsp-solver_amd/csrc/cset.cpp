@@ -277,6 +277,55 @@ int SetManager::transition(int set, const std::vector<int> &first_vals) {
     return found;
 }
 
+int SetManager::pretranslate(long long max_tuples, int max_sets) {
+    int added = 0;
+    for (size_t si = 0; si < sets.size() && (int)sets.size() < max_sets; si++) {  // sets.size() grows while we go
+        if (sets[si]->self_loop) continue;
+        const std::vector<int> fv = sets[si]->first_vars;  // (copy: sets may be re-allocated by transition())
+        long long tuples = 1;
+        for (int v : fv) {
+            tuples *= (long long)ub[v] - lb[v] + 1;
+            if (tuples > max_tuples) break;
+        }
+        if (tuples > max_tuples) continue;
+        std::vector<int> vals(fv.size());
+        for (size_t k = 0; k < fv.size(); k++) vals[k] = lb[fv[k]];
+        for (;;) {
+            // a tuple that violates one of the set's own `first` constraints is never seen at a leaf (the constraint
+            // is enforced at time 0): its translation -- a set with a false constant constraint -- is not worth a set
+            bool reachable = true;
+            {
+                std::map<int, int> vm;
+                for (size_t k = 0; k < fv.size(); k++) vm[fv[k]] = vals[k];
+                HostSet scratch;
+                for (auto &c : sets[si]->cons) {
+                    if (!c.has_first) continue;
+                    Tree *t = translate(scratch, c.root, vm);
+                    std::vector<int> sc;
+                    collect_scope(t, sc);
+                    if (sc.empty() && !is_tautology(t, arrays)) reachable = false;
+                }
+            }
+            if (reachable && !sets[si]->trans.count(vals)) {
+                const int ns = transition((int)si, vals);
+                if (ns < 0) return ns;
+                added++;
+                if ((int)sets.size() >= max_sets) return added;
+            }
+            size_t k = 0;  // next tuple (odometer)
+            for (; k < fv.size(); k++) {
+                if (vals[k] < ub[fv[k]]) {
+                    vals[k]++;
+                    break;
+                }
+                vals[k] = lb[fv[k]];
+            }
+            if (k == fv.size()) break;
+        }
+    }
+    return added;
+}
+
 std::vector<int32_t> SetManager::serialise_set(int set) const {
     std::vector<int32_t> out;
     const HostSet &s = *sets[set];
@@ -573,6 +622,7 @@ int SetManager::compile(FlatProgram &out) {
         ItemDesc small;
     };
     std::map<std::vector<int32_t>, TableCacheEntry> table_cache;
+    std::map<std::vector<int32_t>, std::pair<int32_t, int32_t>> code_cache;
     for (size_t si = 0; si < sets.size(); si++) {
         HostSet &s = *sets[si];
         SetDesc sd{};
@@ -626,13 +676,25 @@ int SetManager::compile(FlatProgram &out) {
             if (c.type == CT_POINT) {
                 bool guards = tree_has_arr(c.root);
                 cd.uses_valid = guards;
-                int depth = 0, max_depth = 0, mask_depth = 0;
-                int rc = compile_expr(c.root, c.scope, guards, out.code, depth, max_depth, mask_depth);
-                if (rc != STCSP_OK) return rc;
-                out.code.push_back(OP_END);
-                if (max_depth > out.max_stack) out.max_stack = max_depth;
+                // identical constraints (the same constraint in two sets) share their program
+                std::vector<int32_t> key;
+                serialise_tree(c.root, key);
+                auto hit = code_cache.find(key);
+                if (hit != code_cache.end()) {
+                    cd.code_off = hit->second.first;
+                    cd.code_len = hit->second.second;
+                } else {
+                    int depth = 0, max_depth = 0, mask_depth = 0;
+                    int rc = compile_expr(c.root, c.scope, guards, out.code, depth, max_depth, mask_depth);
+                    if (rc != STCSP_OK) return rc;
+                    out.code.push_back(OP_END);
+                    if (max_depth > out.max_stack) out.max_stack = max_depth;
+                    cd.code_len = (int32_t)out.code.size() - cd.code_off;
+                    code_cache.emplace(key, std::make_pair(cd.code_off, cd.code_len));
+                }
+            } else {
+                cd.code_len = 0;
             }
-            cd.code_len = (int32_t)out.code.size() - cd.code_off;
             // work items of this constraint (one per enforced time point)
             const int con_abs = (int)out.cons.size();
             if (c.type == CT_NEXT) {
@@ -712,6 +774,7 @@ int SetManager::compile(FlatProgram &out) {
                         it.idx[3] = cd.n_forbidden;
                         it.toff = cd.code_off;
                         it.r1 = cd.uses_valid;
+                        it.r2 = cd.code_len;
                     }
                     it.point = p;
                     it.con = con_abs;
@@ -731,6 +794,8 @@ int SetManager::compile(FlatProgram &out) {
         }
         // items: lane-revised ones first, then the wavefront-revised ones
         sd.item_begin = (int32_t)out.items.size();
+        sd.witem_begin = 0;
+        for (const SetDesc &prev : out.sets) sd.witem_begin += prev.nitems - prev.nsmall;
         sd.nsmall = (int32_t)small_items.size();
         sd.nitems = (int32_t)(small_items.size() + wave_items.size());
         sd.iw = std::max(1, (sd.nitems + 31) / 32);

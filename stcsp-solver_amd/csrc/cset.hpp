@@ -71,6 +71,11 @@ public:
     // next set for a leaf of `set` whose first-variables have the given values (in
     // first_vars order); creates and registers the set / transition when unseen.
     int transition(int set, const std::vector<int> &first_vals);
+    // Translate AHEAD of need: for every set whose captured variables span at most `max_tuples` value tuples,
+    // register the transition of every tuple (and so on for the sets this creates, up to `max_sets` sets), so
+    // that the device never has to stop for a translation of such a set (models with `first x` inside
+    // arithmetic have |D| sets). Returns the number of transitions added, < 0 on error.
+    int pretranslate(long long max_tuples, int max_sets);
     int compile(FlatProgram &out);
     int find_tag(int32_t tag) const;
     // serialised registry exchange for sharded runs (every shard must know every set)

@@ -71,7 +71,7 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
 
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
-        arr_off, code, words;
+        arr_off, code, divmagic, words;
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };
 

@@ -124,7 +124,7 @@ struct WaveEnv {
     int self_loop = 0, nfirst = 0, first_off = 0, trans_begin = 0, trans_count = 0, nitems = 0, nsmall = 0, iw = 1;
     int rows_abs = 0;   // the set's [N*K][iw] dirty rows
     int sweep_abs = 0;  // its packed sweep records
-    int items_abs = 0;  // its ItemDesc records
+    int items_abs = 0;  // the ItemDesc record of its item i (wavefront-revised: i >= nsmall) is at items_abs + 12 i
     int next_abs = -1;  // its eager-arc partner entries (-1: the set has none)
     unsigned long long pm[DR] = {};  // block words (bit l = word q*64 + l) that have an eager partner
     uint32_t smallmask = 0;          // per lane: bits of the lane-revised items in dirty word `lane`
@@ -140,20 +140,30 @@ struct WaveEnv {
 // scope position: varinfo = 1 + slot for lane-enumerated variables (value in lds_vals), 0 for
 // wave-uniform ones (value in curval).
 template <bool L>
-__device__ int eval_program(const Ctx &c, const Img<L> &P, int pc, bool uses_valid, int lane, uint32_t varinfo, int curval,
+__device__ int eval_program(const Ctx &c, const Img<L> &P, int pc0, int code_len, bool uses_valid, int lane, uint32_t varinfo, int curval,
                             const int *lds_vals, int *lds_stk) {
     int t = 0, sp = 0;
     bool valid = true;
     uint32_t dead = 0;
+    // The program itself lives in two VGPRs for the duration of the call (word k in lane k): fetching an
+    // instruction is a v_readlane instead of a dependent LDS / scalar-memory read per instruction.
+    const uint32_t cv0 = lane < code_len ? (uint32_t)P.v(c.o.code + pc0 + lane) : 0u;
+    const uint32_t cv1 = 64 + lane < code_len ? (uint32_t)P.v(c.o.code + pc0 + 64 + lane) : 0u;
+    auto fetch = [&](int rel) -> int {
+        if (rel < 64) return (int)rdlane(cv0, rel);
+        if (rel < 128) return (int)rdlane(cv1, rel - 64);
+        return P.u(c.o.code + pc0 + rel);
+    };
+    int pc = 0;
     for (;;) {
-        int w = P.u(c.o.code + pc++);
+        int w = fetch(pc++);
         int op = w & 255, arg = w >> 8;
         switch (op) {
             case OP_END: return t;
             case OP_CONST:
                 lds_stk[sp * 64 + lane] = t;
                 sp++;
-                t = P.u(c.o.code + pc++);
+                t = fetch(pc++);
                 break;
             case OP_VAR: {
                 lds_stk[sp * 64 + lane] = t;
@@ -254,6 +264,15 @@ __device__ __forceinline__ uint32_t wave_xor32(uint32_t v) {
     v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
     v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
     v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {  // all 64 lanes active
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned long long wave_xor64(unsigned long long v) {
@@ -372,81 +391,25 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, cons
     }
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
 
-    // --- split the NON-SINGLETON scope variables: up to kMaxLowVars of them whose domain sizes
-    // multiply to <= 64 are enumerated ACROSS LANES (lane index = mixed-radix tuple index), the rest
-    // ("high") are stepped wave-uniformly by an odometer. Singletons are just constants.
-    uint32_t varinfo = 0;   // scope lane j: 1 + slot if low
-    int pairbase = 0;       // scope lane j: first pair lane of low var j
-    int pst = 1, pn = 1, pk = 0;  // pair lane: stride / radix / digit it stands for
-    int lane_part = 0;      // tuple lane: bitmap index contribution of the low variables
-    int P = 1, nlow = 0, npairs = 0;
-    unsigned long long highmask = 0, lowmask = 0;
-    int maxn = 1;
-    for (unsigned long long m = __ballot(lane < s && n > 1); m; m &= m - 1) {
-        const int j = __ffsll((long long)m) - 1;
-        const int nj = (int)rdlane((uint32_t)n, j);
-        if (nlow < kMaxLowVars && P * nj <= 64) {
-            const uint32_t Dj = rdlane(D, j);
-            // digit of low variable j in this lane's tuple, and the value bit it stands for. P, nj and
-            // Dj are wave-uniform: powers of two divide by shifting, small domains (the common case:
-            // 0/1 variables) pick the digit-th set bit with two VALU operations per value
-            const int q = (P & (P - 1)) == 0 ? (lane >> (__ffs(P) - 1)) : small_div(lane, P);
-            const int digit = (nj & (nj - 1)) == 0 ? (q & (nj - 1)) : q - nj * small_div(q, nj);
-            int bitpos = 0;
-            if (nj <= 8) {
-                int k = 0;
-                for (uint32_t m = Dj; m; m &= m - 1, k++) bitpos = digit == k ? __ffs((int)m) - 1 : bitpos;
-            } else {
-                bitpos = select_kth_fast(Dj, digit);
-            }
-            lds_vals[nlow * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
-            if (use_bitmap) lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
-            if (lane == j) {
-                varinfo = 1 + nlow;
-                pairbase = npairs;
-            }
-            if (lane >= npairs && lane < npairs + nj) {
-                pst = P;
-                pn = nj;
-                pk = lane - npairs;
-            }
-            lowmask |= 1ull << j;
-            nlow++;
-            P *= nj;
-            npairs += nj;
-        } else {
-            highmask |= 1ull << j;
-            if (nj > maxn) maxn = nj;
-        }
-    }
-    const bool active = lane < P;
-    const bool pairlane = lane < npairs;
-    // pair lane (q,k): the set of tuple lanes whose digit of low variable q equals k is periodic
-    // in the lane index -- build it arithmetically (no ballots)
-    unsigned long long M = 0;
-    if (pairlane) {
-        M = ((1ull << pst) - 1ull) << (pk * pst);
-        int sh = pst * pn;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            if (sh < 64) M |= M << sh;
-            sh <<= 1;
-        }
-        if (P < 64) M &= (1ull << P) - 1ull;
-    }
-    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the
-    // wave-uniform part of that product (the odometer range) is larger than the budget the
-    // revision could never finish, so it is skipped outright. This keeps propagation sound (no
-    // value is ever removed without proof) and the search complete: at a leaf every variable is a
-    // singleton, the product is 1 and the constraint is checked exactly -- the same argument that
-    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield
-    // the same automaton.
+    // --- general revision: enumerate the product of the OPEN (non-singleton) scope variables, 64 tuples per
+    // block (tuple index = block * 64 + lane, decomposed in mixed radix over the open variables in scope
+    // order), evaluate every tuple (bitmap look-up or postfix program), and OR the value bits of the
+    // satisfying tuples into per-variable support sets. Singletons are constants. One short scalar loop over
+    // the open variables per block: no lane/odometer split, no per-(variable, digit) lanes.
+    const unsigned long long openm = __ballot(lane < s && n > 1);
+    const int nopen = __popcll(openm);
+    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the product is
+    // larger than the budget the revision could never finish, so it is skipped outright. This keeps
+    // propagation sound (no value is ever removed without proof) and the search complete: at a leaf every
+    // variable is a singleton, the product is 1 and the constraint is checked exactly -- the same argument that
+    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield the same
+    // automaton. A lane keeps the value bits of its tuple packed in 64 bits (5 per open variable: at most
+    // kMaxOpenVars); the interpreter additionally needs the tuple values in LDS (at most kMaxLowVars).
+    unsigned long long P = 1;
     {
-        const unsigned long long budget = (unsigned long long)(unsigned)(use_bitmap ? c.budget_bitmap : c.budget_code);
-        unsigned long long total_hi = 1;
-        for (unsigned long long hm = highmask; hm && total_hi <= budget; hm &= hm - 1)
-            total_hi *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)hm) - 1);
-        if (total_hi > budget) {
+        const unsigned long long budget = 64ull * (unsigned long long)(unsigned)(use_bitmap ? c.budget_bitmap : c.budget_code);
+        for (unsigned long long m = openm; m && P <= budget; m &= m - 1) P *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)m) - 1);
+        if (P > budget || nopen > kMaxOpenVars || (!use_bitmap && nopen > kMaxLowVars)) {
             if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
             S.n_skipped++;
             return true;
@@ -454,123 +417,89 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, cons
     }
     const unsigned long long t_rv1 = PHASE_NOW();
     (void)t_rv1;
-    bool hit = false;   // pair lanes: this (low var, digit) has a support
-    uint32_t hs = 0;    // scope lanes (high vars): supported value bits
-    int digit_h = 0;    // scope lanes (high vars): odometer digit
-    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;
-    int curval = vlb + curbit;
-    const bool is_high = (highmask >> lane) & 1ull;
-    // bitmap index contribution of the singleton variables (constant for this revision)
-    int base_sum = 0;
-    if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit * mystride : 0);
+    // exact x / n for n <= 32, x < 2^27: mulhi(x, ceil(2^32 / n)) (device_types.hpp kDivMagic, in the image)
+    const uint32_t magic = lane < s ? (uint32_t)G.v(c.o.divmagic + n) : 0u;
+    const int curbit0 = lane < s ? (__ffs((int)D) - 1) : 0;
+    const int curval = vlb + curbit0;  // singletons: their value; open variables: unused
+    // scope lane j of an open variable: 1 + its slot in lds_vals (ascending scope order)
+    const uint32_t varinfo = (lane < s && n > 1) ? 1u + (uint32_t)__popcll(openm & ((1ull << lane) - 1ull)) : 0u;
+    int base_sum = 0;  // bitmap index contribution of the singletons
+    if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit0 * mystride : 0);
     S.n_revs++;
     S.n_wave_revs++;
 #ifdef STCSP_PHASES
-    ws.rv_open += (unsigned)__popcll(lowmask | highmask);
-    ws.rv_lanes += (unsigned)P;
+    ws.rv_open += (unsigned)nopen;
+    ws.rv_lanes += (unsigned)(P < 64 ? P : 64);
 #endif
-    const unsigned nact = (unsigned)P;
-    // stage A: maxn "diagonal" probes (high variable j takes its (it mod n_j)-th value): every
-    // value of every high variable appears once, so loose constraints finish here.
-    // stage B: exhaustive odometer over the high variables, early exit once all is supported.
+    uint32_t hs = 0;  // scope lanes of open variables: supported value bits so far
     bool any_sat = false;
-    unsigned long long iters = 0;
-    int stage_a_left = highmask ? maxn : 1;
-    bool stage_b = false;
-    for (;;) {
-        if (stage_a_left > 0) {
-            if (is_high) {
-                int it = maxn - stage_a_left;
-                curbit = select_kth_fast(D, it - n * small_div(it, n));
-                curval = vlb + curbit;
-            }
-            stage_a_left--;
-        } else if (!stage_b) {
-            stage_b = true;  // first exhaustive tuple block: all high digits 0
-            if (is_high) {
-                digit_h = 0;
-                curbit = __ffs((int)D) - 1;
-                curval = vlb + curbit;
-            }
+    const unsigned nblocks = (unsigned)((P + 63) >> 6);
+    // blocks are visited in a scattered order (b * odd stride mod 2^k, skipping the overshoot) so that the digits
+    // of the slow (high-stride) variables vary early: loose constraints are fully supported after a few blocks
+    unsigned nb2 = 1;
+    while (nb2 < nblocks) nb2 <<= 1;
+    const unsigned bstride = (nb2 >> 1) | (nb2 >> 3) | 1u;  // odd: a full cycle modulo nb2
+    unsigned visited = 0;
+    for (unsigned step = 0; step < nb2 && visited < nblocks; step++) {
+        const unsigned blk = (step * bstride) & (nb2 - 1);
+        if (blk >= nblocks) continue;
+        visited++;
+        const unsigned t = blk * 64u + (unsigned)lane;
+        const bool active = (unsigned long long)t < P;
+        unsigned rem = active ? t : 0u;
+        int bit = base_sum, slot = 0;
+        unsigned long long pack = 0;  // value bit of open variable `slot` in bits [5 slot, 5 slot + 5)
+        for (unsigned long long m = openm; m; m &= m - 1, slot++) {
+            const int j = __ffsll((long long)m) - 1;
+            const uint32_t nj = rdlane((uint32_t)n, j), Dj = rdlane(D, j);
+            const unsigned q = __umulhi(rem, rdlane(magic, j));
+            const int digit = (int)(rem - q * nj);
+            rem = q;
+            const int bitpos = select_kth_fast(Dj, digit);
+            pack |= (unsigned long long)(unsigned)bitpos << (5 * slot);
+            if (use_bitmap)
+                bit += bitpos * (int)rdlane((uint32_t)mystride, j);
+            else
+                lds_vals[slot * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
         }
         int res;
-        if (use_bitmap) {
-            int bit = lane_part + base_sum;
-            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
-                const int j = __ffsll((long long)hm) - 1;
-                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
-            }
+        if (use_bitmap)
             res = active ? (int)(((uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
-        } else {
-            res = eval_program<L>(c, G, C.code_off, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
-        }
-        S.n_evals += nact;
+        else
+            res = eval_program<L>(c, G, C.code_off, C.code_len, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
+        S.n_evals += (unsigned)(P - (unsigned long long)blk * 64u < 64 ? P - (unsigned long long)blk * 64u : 64);
 #ifdef STCSP_PHASES
         ws.rv_blocks++;
 #endif
-        const unsigned long long sm = __ballot(active && res != 0);
-        if (sm) {
+        const bool sat = active && res != 0;
+        if (__ballot(sat)) {
             any_sat = true;
-            if (pairlane && (M & sm)) hit = true;
-            if (is_high) hs |= 1u << curbit;
-        }
-        if (__ballot((pairlane && !hit) || (is_high && hs != D)) == 0) break;  // everything supported
-        if (stage_a_left > 0) continue;
-        if (!highmask) break;  // no high variables: the lanes covered the whole product
-        if (!stage_b) continue;
-        // advance the odometer (wave-uniform carry chain over the high variables)
-        bool carry = true;
-        for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
-            const int j = __ffsll((long long)hm) - 1;
-            int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
-            const int nj = (int)rdlane((uint32_t)n, j);
-            if (dj == nj)
-                dj = 0;
-            else
-                carry = false;
-            if (lane == j) {
-                digit_h = dj;
-                curbit = select_kth_fast(D, dj);
-                curval = vlb + curbit;
+            slot = 0;
+            for (unsigned long long m = openm; m; m &= m - 1, slot++) {
+                const int j = __ffsll((long long)m) - 1;
+                const int bitpos = (int)(pack >> (5 * slot)) & 31;
+                const uint32_t got = wave_or32(sat ? 1u << bitpos : 0u);
+                if (lane == j) hs |= got;
             }
-        }
-        if (carry) break;  // wrapped around: product exhausted
-        if (++iters > (1ull << 22)) {
-            S.err = max(S.err, (unsigned)ERR_WATCHDOG);
-            return false;
+            if (__ballot(((openm >> lane) & 1ull) && hs != D) == 0) break;  // everything is supported
         }
     }
     const unsigned long long t_rv2 = PHASE_NOW();
     (void)t_rv2;
     // --- write back. No satisfying tuple at all: wipe-out. Otherwise singletons are supported by
-    // construction and only the enumerated / stepped variables can lose values.
+    // construction and only the open variables can lose values.
     if (!any_sat) return false;
-    const unsigned long long hitmask = __ballot(pairlane && hit);
-    for (unsigned long long m = lowmask | highmask; m; m &= m - 1) {
+    for (unsigned long long m = __ballot(((openm >> lane) & 1ull) && hs != D); m; m &= m - 1) {
         const int j = __ffsll((long long)m) - 1;
-        const uint32_t Dj = rdlane(D, j);
-        uint32_t newD;
-        if ((lowmask >> j) & 1ull) {
-            const uint32_t dig = (uint32_t)(hitmask >> (int)rdlane((uint32_t)pairbase, j));
-            bool keep = false;
-            if (lane < 32 && ((Dj >> lane) & 1u)) keep = (dig >> __popc(Dj & ((1u << lane) - 1u))) & 1u;
-            newD = (uint32_t)__ballot(keep);
-        } else {
-            newD = rdlane(hs, j);
-        }
+        const uint32_t newD = rdlane(hs, j);
         if (newD == 0) return false;
-        if (newD != Dj) {
-            const int vj = (int)rdlane((uint32_t)var, j);
-            {
-                const int w = p * c.N + vj;
+        const int w = p * c.N + (int)rdlane((uint32_t)var, j);
 #pragma unroll
-                for (int q = 0; q < DR; q++)
-                    if ((w >> 6) == q && ((pm[q] >> (w & 63)) & 1ull)) pruned = true;  // a next arc hangs on this word
-            }
-            dom.set(p * c.N + vj, newD, lane);
-            if (lane == 0) ldom[p * c.N + vj] = (int)newD;  // keep the sweep's LDS copy of the block current
-            if (lane < S.iw) dirtyw |= (uint32_t)G.v(S.rows_abs + (p * c.N + vj) * S.iw + lane);
-        }
+        for (int q = 0; q < DR; q++)
+            if ((w >> 6) == q && ((pm[q] >> (w & 63)) & 1ull)) pruned = true;  // a next arc hangs on this word
+        dom.set(w, newD, lane);
+        if (lane == 0) ldom[w] = (int)newD;  // keep the sweep's LDS copy of the block current
+        if (lane < S.iw) dirtyw |= (uint32_t)G.v(S.rows_abs + w * S.iw + lane);
     }
     // one revision is a fixpoint for this constraint at this point: no need to revisit it for
     // its own changes (supports are whole tuples of surviving values)
@@ -601,10 +530,10 @@ __device__ __forceinline__ void load_env(const Ctx &c, const Img<L> &P, int set,
     E.iw = STCSP_SD(iw);
     const int item_begin = STCSP_SD(item_begin), next_off = STCSP_SD(next_off);
     E.rows_abs = c.o.itemrows + STCSP_SD(itemrows_off);
-#undef STCSP_SD
     E.sweep_abs = c.o.sweep + item_begin * 4;
-    E.items_abs = c.o.items + item_begin * (int)(sizeof(ItemDesc) / 4);
+    E.items_abs = c.o.items + (STCSP_SD(witem_begin) - E.nsmall) * (int)(sizeof(ItemDesc) / 4);  // wavefront-revised items only
     E.next_abs = next_off >= 0 ? c.o.nextpart + next_off : -1;
+#undef STCSP_SD
     {
         const int left = E.nsmall - lane * 32;
         E.smallmask = (lane < E.iw && left > 0) ? (left >= 32 ? 0xffffffffu : ((1u << left) - 1u)) : 0u;
@@ -954,6 +883,8 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                     }
 #endif
                 }
+                STCSP_REJOIN();
+                S.n_revs += (unsigned)__popcll(dmask);  // (after the lane-predicated part: keeps the counter wave-uniform)
             }
             dirtyw &= ~smallmask;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1003,6 +934,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         C.n_forbidden = STCSP_ID(idx[3]);
         C.code_off = STCSP_ID(toff);
         C.uses_valid = STCSP_ID(r1);
+        C.code_len = STCSP_ID(r2);
 #undef STCSP_ID
         bool pruned = false;
         consistent = revise_point<DR, L, LITE>(c, P, S, C, item, ipoint, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, pruned);

@@ -17,7 +17,8 @@ namespace stcsp {
 constexpr int kRegions = 32;        // cursor shards per segment (spreads allocation atomics)
 constexpr int kMaxDomRegs = 4;      // N*K <= 64 * kMaxDomRegs words live in VGPRs, lane-striped
 constexpr int kCompactSweepItems = 128;  // sets with more small items than this sweep over a compacted dirty list
-constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revision (2^6 = 64)
+constexpr int kMaxLowVars = 8;      // open scope variables of an INTERPRETED constraint one revision enumerates (tuple values in LDS)
+constexpr int kMaxOpenVars = 12;    // open scope variables of any general revision (value bits packed 5 x 12 in a register pair)
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
@@ -90,7 +91,7 @@ struct ItemDesc {
     int32_t idx[4];       // block word indices p*N+v.  NEXT: idx[0] = (p,X), idx[1] = (p+1,Y)
                           // IT_WAVE: the constraint's scope_off, bitmap_off, stride_off, n_forbidden (ConDesc)
     int32_t toff;         // IT_SMALL: into tables[], one 32-bit row per tuple of variables 1..3; IT_WAVE: code_off
-    int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2; IT_WAVE: r1 = uses_valid
+    int32_t r1, r2;       // IT_SMALL: radices (initial domain sizes) of variables 1 and 2; IT_WAVE: r1 = uses_valid, r2 = code_len
     int32_t aux;          // NEXT: lbX - lbY ; UNTIL: ordinal ; SMALL: number of table rows
 };
 
@@ -132,6 +133,9 @@ struct SetDesc {          // one constraint set (entry of Solver::seenConstraint
     int32_t itemrows_off; // into itemrows[]: [N*K][iw] rows: items that read block word (p,v)
     int32_t next_off;     // into nextpart[]: [N*K][2] partner entries of the X == next Y arcs that are kept
                           // consistent eagerly (close_next) instead of being items; -1: none in this set
+    int32_t witem_begin;  // number of wavefront-revised items of the sets before this one: the device image holds
+                          // the ItemDesc records of those items only (item i >= nsmall -> record witem_begin + i - nsmall)
+    int32_t pad[3];
 };
 // nextpart[word] = two entries; entry: 0 = none, else (partner block word + 1) | (lbX - lbY + 64) << 16 |
 // side << 24 (shift clamped to [-32, 32]; side 0: this word is X[p] and the partner Y[p+1], side 1: this

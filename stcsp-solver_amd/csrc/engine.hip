@@ -245,11 +245,25 @@ struct stcsp_engine {
         o.trans = put(prog.trans.data(), prog.trans.size() * sizeof(TransDesc));
         o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
         o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
+        {
+            // x / n == mulhi(x, ceil(2^32 / n)) for n <= 32, x < 2^27 (mixed-radix tuple decomposition of the general revision)
+            uint32_t magic[33] = {0};
+            for (uint32_t n = 1; n <= 32; n++) magic[n] = (uint32_t)((0x100000000ull + n - 1) / n);
+            magic[1] = 0xffffffffu;  // n = 1 never divides here (singletons are not enumerated)
+            o.divmagic = put(magic, sizeof magic);
+        }
         cut();
         o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
         cut();
         o.hot_words = (int)img.size();
-        o.items = put(prog.items.data(), prog.items.size() * sizeof(ItemDesc));
+        {
+            // ItemDesc records of the wavefront-revised items only (the lane-revised ones are read through their
+            // packed sweep records), set after set: SetDesc::witem_begin
+            std::vector<ItemDesc> witems;
+            for (const SetDesc &sd : prog.sets)
+                witems.insert(witems.end(), prog.items.begin() + sd.item_begin + sd.nsmall, prog.items.begin() + sd.item_begin + sd.nitems);
+            o.items = put(witems.data(), witems.size() * sizeof(ItemDesc));
+        }
         o.scope = put(prog.scope.data(), prog.scope.size() * 4);
         o.strides = put(prog.strides.data(), prog.strides.size() * 4);
         cut();
@@ -366,6 +380,16 @@ struct stcsp_engine {
         if (const char *ev = getenv("STCSP_BUDGET_BITMAP")) ctx.budget_bitmap = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_BUDGET_CODE")) ctx.budget_code = std::max(1, atoi(ev));
         ctx.rank = opt.rank;
+        // constraint sets whose captured `first` variables span few value tuples are translated ahead of need
+        // (SURVEY 8(f) row 1): the device then never stops for them. STCSP_PRETRANSLATE=<tuples> (0 = off).
+        {
+            long long tuples = 4096;
+            if (const char *ev = getenv("STCSP_PRETRANSLATE")) tuples = atoll(ev);
+            if (tuples > 0) {
+                const int pre = mgr.pretranslate(tuples, 256);
+                if (pre < 0) return fail(pre, "%s", mgr.error.c_str());
+            }
+        }
         DR = (N * K + 63) / 64;
         if (DR == 3) DR = 4;
         HIPCHK(d_arr_data.upload(mgr.array_data));
@@ -538,6 +562,7 @@ struct stcsp_engine {
         n_states = 0;
         truncated = false;
         levels = 0;
+        translation_stops = 0;
         finished = false;
         exp_on_device = false;
         ev_used = 0;
@@ -691,9 +716,11 @@ struct stcsp_engine {
         return STCSP_OK;
     }
 
+    long long translation_stops = 0;
     int service_misses() {
         uint32_t nm = h_ctl[L.misc0 + MISC_NMISS * CST];
         if (!nm) return STCSP_OK;
+        translation_stops++;
         uint32_t n = std::min<uint32_t>(nm, (uint32_t)ctx.miss_cap);
         HIPCHK(hipMemcpyAsync(h_miss, d_miss.p, (size_t)n * kMissStride * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -832,6 +859,7 @@ struct stcsp_engine {
         ctr.wave_revisions = (int64_t)tot[ST_WAVEREVS];
         ctr.sweeps = (int64_t)tot[ST_SWEEPS];
         ctr.skipped_revisions = (int64_t)tot[ST_SKIPPED];
+        ctr.translation_stops = translation_stops;
 #ifdef STCSP_PHASES
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: node load %.0f | process_node %.0f (of which sweeps %.0f, wavefront revisions %.0f) | emit/commit %.0f | total %.0f (nodes %llu)\n",
@@ -1267,6 +1295,14 @@ struct stcsp_engine {
         return STCSP_OK;
     }
 
+    // Solver::seenConstraints = the initial set + every set a leaf translated to = the distinct set ids of the
+    // table's states (the registry may hold more: sets translated ahead of need)
+    int32_t used_sets() const {
+        std::vector<int32_t> u(r_cid.begin(), r_cid.end());
+        u.push_back(0);
+        std::sort(u.begin(), u.end());
+        return (int32_t)(std::unique(u.begin(), u.end()) - u.begin());
+    }
     int export_result(stcsp_result *res) {
         auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipSetDevice(device));
@@ -1289,7 +1325,7 @@ struct stcsp_engine {
             res->state_sig = r_sig.data();
             res->n_edges = (int64_t)E;
             res->n_vars = N;
-            res->n_constraint_sets = (int32_t)mgr.sets.size();
+            res->n_constraint_sets = used_sets();
             res->var_is_signature = r_issig.data();
             res->root_final = mgr.n_until_cons == 0;
             res->truncated = truncated;
@@ -1372,7 +1408,7 @@ struct stcsp_engine {
         res->edge_dst = r_edst.data();
         res->edge_values = r_eval.data();
         res->n_vars = N;
-        res->n_constraint_sets = (int32_t)mgr.sets.size();
+        res->n_constraint_sets = sharded ? (int32_t)mgr.sets.size() : used_sets();
         res->var_is_signature = r_issig.data();
         res->root_final = mgr.n_until_cons == 0;
         res->truncated = truncated;

@@ -922,6 +922,13 @@ int stcsp_merge_shards(const stcsp_result *const *shards, int n, stcsp_merged **
     m.res.edge_dst = m.edst.data();
     m.res.edge_values = m.eval.data();
     m.res.var_is_signature = m.issig.data();
+    {
+        // Solver::seenConstraints holds the initial set and every set some leaf translated to, i.e. the distinct
+        // set ids of the table's states (a shard's own registry may hold more: sets it translated ahead of need)
+        std::set<int32_t> used(m.cid.begin(), m.cid.end());
+        used.insert(0);
+        nsets = (int32_t)used.size();
+    }
     m.res.n_constraint_sets = nsets;
     m.res.truncated = truncated;
     m.res.counters = ctr;

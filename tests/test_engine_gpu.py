@@ -155,6 +155,40 @@ def test_engine_pool_growth_paths(stcsp, golden, monkeypatch):
         assert r.n_states == golden[name]["node"] or golden[name]["fail"] > 0
 
 
+MANY_SETS = [
+    # `first x` inside arithmetic: one constraint set per captured value (33 = 1 + |D(x)|)
+    ("var x:[0,31]; var y:[0,31]; var z:[0,1]; y + z == first x; next z == 1 - z;", 33),
+    # two captured variables, one of them pinned by its own `first` constraint (1 + 21 * 2)
+    ("var x:[0,20]; var w:[0,3]; var y:[0,24]; var z:[0,1]; y == first x + first w + z; next z == 1 - z; first w <= 1;", 43),
+]
+
+
+@pytest.mark.parametrize("text,n_sets", MANY_SETS)
+def test_engine_many_constraint_sets_never_stop_the_device(stcsp, RefOracle, monkeypatch, text, n_sets):
+    """SURVEY 8(f) row 1 (constraintTranslate per leaf, src/constraint.cpp:466-548 / solveralgorithm.cpp:755-805):
+    sets whose captured `first` variables span few value tuples are translated ahead of need, so the device never
+    stops for the host (translation_stops == 0); switched off, the same model stops once per batch of new sets.
+    Either way: the reference-faithful oracle's automaton and its number of constraint sets."""
+    m = stcsp.Model(text=text)
+    o = RefOracle(m)
+    ro = o.solve()
+    ao, _ = finish(o, ro)
+    assert ro.n_constraint_sets == n_sets
+    e = stcsp.Engine(m)
+    r = e.solve()
+    a, _ = finish(e, r)
+    assert a.canonical() == ao.canonical()
+    assert r.n_constraint_sets == n_sets
+    assert r.counters.translation_stops == 0
+    assert r.counters.dominance == ro.counters.dominance  # order-independent (SURVEY 8c, L2)
+    monkeypatch.setenv("STCSP_PRETRANSLATE", "0")
+    e2 = stcsp.Engine(m)
+    r2 = e2.solve()
+    a2, _ = finish(e2, r2)
+    assert a2.canonical() == ao.canonical() and r2.n_constraint_sets == n_sets
+    assert r2.counters.translation_stops >= 1
+
+
 def test_engine_array_validity_semantics(stcsp, RefOracle):
     """Out-of-range array lookups (reference `valid` flag), also under branches that are not
     taken: tabulated by the host evaluator and checked against the oracle."""

@@ -31,6 +31,23 @@ def test_normalisation_worked_examples(stcsp):
     assert m.var_bounds()[m.var_names.index("_V3")] == (-1, 2)
 
 
+def test_normalisation_fixtures(stcsp):
+    """Vectors that do not come from the product: tests/golden/frontend_normalised.json holds the normalised
+    constraint lists and auxiliary-variable bounds derived by hand from the reference's constraintNormalise
+    (src/solveralgorithm.cpp:60-332) for its quirk cases (`not` bounds, @ after next, nested fby, the sign cases
+    of `*`, ...). The oracle and the engine both consume what this front end produces, so this is what keeps the
+    fuzz agreement from being front-end-against-itself."""
+    import json
+    doc = json.loads((Path(__file__).resolve().parent / "golden" / "frontend_normalised.json").read_text())
+    assert len(doc["cases"]) >= 20
+    for case in doc["cases"]:
+        m = stcsp.Model(text=case["text"])
+        got = [m.constraint_string(i) for i in range(m.n_constraints)]
+        assert got == case["constraints"], case["name"]
+        aux = [[n, lo, hi] for n, (lo, hi) in zip(m.var_names, m.var_bounds()) if n.startswith("_V")]
+        assert aux == case["aux"], case["name"]
+
+
 def test_lexer_corner_cases(stcsp):
     ok = "var x:[0,3]; // comment\nvar y : [ -1 , 2 ];\n' quote comment\n/* block */ x - 1 == y; x <= 3;"
     m = stcsp.Model(text=ok)

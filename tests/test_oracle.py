@@ -137,3 +137,22 @@ def test_array_validity_semantics(stcsp, RefOracle, FrontierModel, text):
     af, _ = finish(f, f.solve())
     assert af.canonical() == ao.canonical()
     assert ao.n_live_states > 1
+
+
+@pytest.mark.parametrize("name", ["juggling_b4_f5", "partialorder_10", "digitinvader2", "juggling_b4_f4_nosym"])
+def test_parallel_restatement_matches_reference_golden(stcsp, oracle_lib, RefOracle, golden, name):
+    """bench.py's all-cores CPU leg (oracle/ref_dfs.cpp struct Shared: workers over the automaton's states):
+    the reference's recorded automaton and its order-independent counters."""
+    import ctypes as C
+    oracle_lib.stcsp_oracle_solve_parallel.argtypes = [C.c_void_p, C.c_int, C.POINTER(stcsp.Result)]
+    m = stcsp.Model.from_name(name)
+    o = RefOracle(m)
+    for threads in (1, 4):
+        o._check(oracle_lib.stcsp_oracle_solve_parallel(o._h, threads, C.byref(o.result)))
+        r = o.result
+        a = o.automaton(r).traverse().renumber()
+        g = golden[name]
+        assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (g["states"], g["edges"], g["canonical_sha256"])
+        assert r.counters.dominance == g["dom"]
+        if g["fail"] == 0:
+            assert r.n_states == g["node"] and r.counters.search_nodes == g["search"]

@@ -20,11 +20,13 @@ def free_port():
     return p
 
 
-def launch(world, name, kind, tmp_path, timeout=300):
+def launch(world, name, kind, tmp_path, timeout=300, env=None):
+    import os
     port = free_port()
     out = tmp_path / "merged.json"
     procs = [subprocess.Popen([sys.executable, str(REPO / "tests" / "_sharded_worker.py"), str(r), str(world), str(port),
-                               name, kind, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               name, kind, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, **(env or {})))
              for r in range(world)]
     logs = []
     for p in procs:
@@ -89,6 +91,93 @@ def test_sharded_synthetic_gloo_cpu(stcsp, oracle_lib, RefOracle, tmp_path, worl
     r = launch(world, spec, "fmodel", tmp_path)
     assert r["sha"] == sha
     assert r["dom"] == dom
+
+
+# Frontier redistribution (the branch case of the search, src/solveralgorithm.cpp:911-939, is the
+# work that moves). NO_LEAF instances never reach a leaf (pure refutation, like BASELINE config 4 at 64 x 32): without
+# redistribution every shard but the root's would stay idle for ever. SHARE: tiny instances must share early.
+NO_LEAF = ["synth:24,8,125,4,7", "synth:16,8,95,4,20261003"]
+SHARE = {"STCSP_TEST_BUDGET_ROUNDS": "1", "STCSP_TEST_SHARE": "2"}
+
+
+def test_plan_transfers_is_deterministic_and_balancing():
+    import importlib
+    sh = importlib.import_module("stcsp-solver_amd.sharded")
+    assert sh.plan_transfers([0, 0, 0]) == [[0] * 3] * 3
+    assert sh.plan_transfers([10, 9, 11]) == [[0] * 3] * 3          # balanced enough
+    p = sh.plan_transfers([100, 0, 0, 0])                            # scatter from the root's shard
+    assert p[0] == [0, 25, 25, 25] and all(sum(r) == 0 for r in p[1:])
+    p = sh.plan_transfers([90, 10, 0])
+    left = [90, 10, 0]
+    after = [left[r] - sum(p[r]) + sum(p[q][r] for q in range(3)) for r in range(3)]
+    assert sum(after) == 100 and max(after) - min(after) <= 2
+    assert sh.plan_transfers([5, 0]) == [[0, 2], [0, 0]]
+
+
+@pytest.mark.parametrize("world,spec", [(2, NO_LEAF[0]), (3, NO_LEAF[0]), (4, NO_LEAF[0])])
+def test_frontier_redistribution_no_leaf_gloo_cpu(stcsp, oracle_lib, FrontierModel, RefOracle, tmp_path, world, spec):
+    """Every shard gets work although nobody ever reaches a leaf; the search tree is the unsharded one (open
+    nodes are self-contained: whoever expands one produces the same children), so the counts add up exactly."""
+    from _sharded_worker import load_model
+    m = load_model(stcsp, spec)
+    f = FrontierModel(m)
+    r1 = f.solve()
+    assert r1.counters.leaves == 0 and r1.counters.search_nodes > 100
+    r = launch(world, spec, "fmodel", tmp_path, env=SHARE)
+    assert all(n > 0 for n in r["rank_nodes"]), r["rank_nodes"]
+    assert sum(r["rank_nodes"]) == r1.counters.search_nodes
+    assert r["fails"] == r1.counters.fails
+    assert sum(r["donated"]) == sum(r["adopted"]) > 0
+    canon, sha, dom = reference_of(stcsp, RefOracle, spec)
+    assert r["sha"] == sha
+
+
+@pytest.mark.parametrize("world,name", [(2, "juggling_b4_f5"), (3, "digitinvader2"), (2, "partialorder_10"), (3, SYNTH_SMALL[2])])
+def test_frontier_redistribution_parity_gloo_cpu(stcsp, oracle_lib, RefOracle, golden, tmp_path, world, name):
+    """Redistribution switched on aggressively on terminating instances (incl. `first` sets that travel):
+    automaton parity with the reference's recorded values / the reference-faithful oracle."""
+    r = launch(world, name, "fmodel", tmp_path, env=SHARE)
+    if name in golden:
+        g = golden[name]
+        assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+        assert r["dom"] == g["dom"]
+    else:
+        canon, sha, dom = reference_of(stcsp, RefOracle, name)
+        assert r["sha"] == sha and r["dom"] == dom
+    assert sum(r["donated"]) == sum(r["adopted"])
+    if name in ("partialorder_10", SYNTH_SMALL[2]):
+        assert sum(r["donated"]) > 0  # (the small juggling / digitinvader frontiers may never hold enough to share)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec", [(2, NO_LEAF[0]), (3, NO_LEAF[0])])
+def test_frontier_redistribution_no_leaf_hip_one_gpu(stcsp, oracle_lib, FrontierModel, tmp_path, world, spec):
+    """The same with HIP-engine shards on one GPU (k_donate / k_adopt, budgeted expand_local)."""
+    from _sharded_worker import load_model
+    m = load_model(stcsp, spec)
+    f = FrontierModel(m)
+    r1 = f.solve()
+    r = launch(world, spec, "hip", tmp_path, env=SHARE)
+    assert all(n > 0 for n in r["rank_nodes"]), r["rank_nodes"]
+    assert sum(r["rank_nodes"]) == r1.counters.search_nodes
+    assert r["fails"] == r1.counters.fails
+    assert sum(r["donated"]) == sum(r["adopted"]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,name", [(2, "juggling_b4_f5"), (3, "digitinvader3"), (2, "partialorder_12"), (3, SYNTH_SMALL[2])])
+def test_frontier_redistribution_parity_hip_one_gpu(stcsp, oracle_lib, RefOracle, golden, tmp_path, world, name):
+    r = launch(world, name, "hip", tmp_path, env=SHARE)
+    if name in golden:
+        g = golden[name]
+        assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+        assert r["dom"] == g["dom"]
+    else:
+        canon, sha, dom = reference_of(stcsp, RefOracle, name)
+        assert r["sha"] == sha and r["dom"] == dom
+    assert sum(r["donated"]) == sum(r["adopted"])
+    if name in ("partialorder_12", SYNTH_SMALL[2]):
+        assert sum(r["donated"]) > 0
 
 
 @pytest.mark.gpu
