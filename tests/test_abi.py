@@ -46,7 +46,7 @@ def test_abi_struct_sizes(stcsp):
     # mirrors of include/stcsp_engine.h (LP64)
     assert C.sizeof(stcsp.Node) == 24
     assert C.sizeof(stcsp.Options) == 40
-    assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 24
+    assert C.sizeof(stcsp.Counters) == 8 * 8 + 2 * 8 + 8 + 8 + 24 + 8  # + translation_stops
     assert C.sizeof(stcsp.PostOptions) == 16
     assert C.sizeof(stcsp.PostResult) == 72
 
