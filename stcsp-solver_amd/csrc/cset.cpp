@@ -529,21 +529,20 @@ int SetManager::eval_tree(const Tree *t, const std::vector<int> &scope, const in
 //   small  (arity <= 4, <= kSmallMaxRows rows): one 32-bit row of allowed values of the "word"
 //          variable (the widest one) per tuple of the other variables -- one lane revises it;
 //   bitmap (product <= kBitmapMaxBits): one bit per tuple -- the wavefront revises it with a
-//          lookup in place of interpreting the postfix program;
+//          lookup in place of interpreting the postfix program; up to kBitmapMaxBitsDevice when the
+//          engine tabulates on the device (the entry is left `pending`);
 //   otherwise the program is interpreted.
-void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, std::vector<ItemDesc> &small, bool &is_small) {
-    is_small = false;
-    cd.bitmap_off = -1;
-    cd.stride_off = 0;
-    cd.n_forbidden = -1;
+void SetManager::build_entry(const HostCon &c, TableEntry &e) {
+    e = TableEntry();
     const int s = (int)c.scope.size();
     if (c.type != CT_POINT || s == 0) return;
     std::vector<int> size(s);
     long long product = 1;
+    const long long limit = device_tabulation ? kBitmapMaxBitsDevice : kBitmapMaxBits;
     for (int j = 0; j < s; j++) {
         size[j] = ub[c.scope[j]] - lb[c.scope[j]] + 1;
         product *= size[j];
-        if (product > kBitmapMaxBits) return;
+        if (product > limit) return;
     }
     std::vector<int> vals(s), bit(s, 0);
     auto holds = [&]() {
@@ -562,10 +561,8 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
         ItemDesc it{};
         it.type = IT_SMALL;
         it.arity = s;
-        // rows are fetched four at a time (128-bit reads): the table starts on a 4-word boundary
-        // and every run of r1 rows is padded to a multiple of 4 (small_row_stride)
-        while (out.tables.size() & 3) out.tables.push_back(0u);
-        it.toff = (int32_t)out.tables.size();
+        it.toff = 0;  // relative to the entry's words; rows are fetched four at a time (128-bit reads): the
+                      // table is placed on a 4-word boundary and every run of r1 rows is padded to a multiple of 4
         it.r1 = others.size() > 0 ? size[others[0]] : 1;
         it.r2 = others.size() > 1 ? size[others[1]] : 1;
         int r3 = others.size() > 2 ? size[others[2]] : 1;
@@ -584,23 +581,26 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
                         bit[w] = b0;
                         if (holds()) row |= 1u << b0;
                     }
-                    out.tables.push_back(row);
+                    e.words.push_back(row);
                     if (b1 == it.r1 - 1)
-                        for (int pad = it.r1; pad < small_row_stride(it.r1); pad++) out.tables.push_back(0u);
+                        for (int pad = it.r1; pad < small_row_stride(it.r1); pad++) e.words.push_back(0u);
                 }
-        small.push_back(it);
-        is_small = true;
+        e.small = it;
+        e.is_small = true;
         return;
     }
-    cd.stride_off = (int32_t)out.strides.size();
     long long st = 1;
     for (int j = 0; j < s; j++) {
-        out.strides.push_back((int32_t)st);
+        e.strides.push_back((int32_t)st);
         st *= size[j];
     }
-    cd.bitmap_off = (int32_t)out.tables.size();
-    out.tables.resize(out.tables.size() + (size_t)((product + 31) / 32), 0u);
-    uint32_t *bm = out.tables.data() + cd.bitmap_off;
+    e.bitmap = true;
+    e.words.assign((size_t)((product + 31) / 32), 0u);
+    if (product > kBitmapMaxBits) {  // the device fills it in (engine.hip: k_tabulate), then store_tabulated()
+        e.pending = true;
+        return;
+    }
+    uint32_t *bm = e.words.data();
     for (long long t = 0; t < product; t++) {
         long long rem = t;
         for (int j = 0; j < s; j++) {
@@ -610,18 +610,27 @@ void SetManager::build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, s
         if (holds()) bm[t >> 5] |= 1u << (t & 31);
     }
     long long allowed = 0;
-    for (size_t w = 0; w < (size_t)((product + 31) / 32); w++) allowed += __builtin_popcount(bm[w]);
-    cd.n_forbidden = product - allowed <= kFewForbidden ? (int32_t)(product - allowed) : -1;
+    for (uint32_t wd : e.words) allowed += __builtin_popcount(wd);
+    e.n_forbidden = product - allowed <= kFewForbidden ? (int32_t)(product - allowed) : -1;
+}
+
+void SetManager::store_tabulated(const std::vector<int32_t> &key, const uint32_t *words, size_t n, long long product) {
+    auto it = table_cache.find(key);
+    if (it == table_cache.end() || it->second.words.size() != n) return;
+    TableEntry &e = it->second;
+    std::copy(words, words + n, e.words.begin());
+    e.pending = false;
+    long long allowed = 0;  // (bits beyond the product in the last word are zero: k_tabulate masks them)
+    for (uint32_t wd : e.words) allowed += __builtin_popcount(wd);
+    e.n_forbidden = product - allowed <= kFewForbidden ? (int32_t)(product - allowed) : -1;
 }
 
 int SetManager::compile(FlatProgram &out) {
     out = FlatProgram();
-    struct TableCacheEntry {
-        int32_t bitmap_off, stride_off, n_forbidden;
-        bool is_small;
-        ItemDesc small;
+    struct Placed {  // where a cached table sits in THIS program image
+        int32_t off, stride_off;
     };
-    std::map<std::vector<int32_t>, TableCacheEntry> table_cache;
+    std::map<std::vector<int32_t>, Placed> placed;
     std::map<std::vector<int32_t>, std::pair<int32_t, int32_t>> code_cache;
     for (size_t si = 0; si < sets.size(); si++) {
         HostSet &s = *sets[si];
@@ -741,22 +750,51 @@ int SetManager::compile(FlatProgram &out) {
                 it.aux = c.until_ordinal;
                 small_items.push_back(it);
             } else if (c.type == CT_POINT && !c.scope.empty()) {
-                // identical constraints (e.g. the same constraint in two sets) share their tables
+                // identical constraints (e.g. the same constraint in two sets, or the same one at the next compile)
+                // share their tables: table_cache holds the tabulated form, `placed` its position in this image
                 std::vector<int32_t> key;
                 serialise_tree(c.root, key);
-                auto hit = table_cache.find(key);
+                auto ce = table_cache.find(key);
+                if (ce == table_cache.end()) {
+                    ce = table_cache.emplace(key, TableEntry()).first;
+                    build_entry(c, ce->second);
+                }
+                const TableEntry &te = ce->second;
                 std::vector<ItemDesc> proto;
-                bool is_small = false;
-                if (hit != table_cache.end()) {
-                    cd.bitmap_off = hit->second.bitmap_off;
-                    cd.stride_off = hit->second.stride_off;
-                    cd.n_forbidden = hit->second.n_forbidden;
-                    is_small = hit->second.is_small;
-                    if (is_small) proto.push_back(hit->second.small);
-                } else {
-                    build_tables(c, cd, out, proto, is_small);
-                    TableCacheEntry e{cd.bitmap_off, cd.stride_off, cd.n_forbidden, is_small, is_small ? proto[0] : ItemDesc{}};
-                    table_cache.emplace(key, e);
+                const bool is_small = te.is_small;
+                cd.bitmap_off = -1;
+                cd.stride_off = 0;
+                cd.n_forbidden = -1;
+                if (te.is_small || te.bitmap) {
+                    auto pl = placed.find(key);
+                    if (pl == placed.end()) {
+                        while (out.tables.size() & 3) out.tables.push_back(0u);
+                        Placed np{(int32_t)out.tables.size(), (int32_t)out.strides.size()};
+                        out.tables.insert(out.tables.end(), te.words.begin(), te.words.end());
+                        out.strides.insert(out.strides.end(), te.strides.begin(), te.strides.end());
+                        pl = placed.emplace(key, np).first;
+                        if (te.pending) {
+                            TabulateTodo td;
+                            td.key = key;
+                            td.tables_off = np.off;
+                            td.product = 1;
+                            for (int v : c.scope) td.product *= (long long)ub[v] - lb[v] + 1;
+                            td.code_off = cd.code_off;
+                            td.code_len = cd.code_len;
+                            td.uses_valid = cd.uses_valid;
+                            td.scope.assign(c.scope.begin(), c.scope.end());
+                            out.todo.push_back(td);
+                        }
+                    }
+                    if (te.is_small) {
+                        ItemDesc it = te.small;
+                        it.toff = pl->second.off;
+                        proto.push_back(it);
+                    } else {
+                        cd.bitmap_off = pl->second.off;
+                        cd.stride_off = pl->second.stride_off;
+                        cd.n_forbidden = te.n_forbidden;
+                    }
                 }
                 for (int p = 0; p < cd.npoints; p++) {
                     ItemDesc it{};

@@ -39,7 +39,28 @@ struct HostSet {
     TreeArena arena;
 };
 
+// Tabulated form of one point constraint. Kept across compiles (keyed by the serialised tree): a recompile after
+// a new constraint set only tabulates the constraints it has not seen yet.
+struct TableEntry {
+    bool is_small = false;        // rows for the lane-per-item sweep (ItemDesc proto, toff relative to `words`)
+    ItemDesc small{};
+    bool bitmap = false;          // one bit per tuple of the full initial product
+    bool pending = false;         // bitmap still to be tabulated -- on the device (engine.hip k_tabulate)
+    std::vector<uint32_t> words;
+    std::vector<int32_t> strides;
+    int32_t n_forbidden = -1;
+};
+// A bitmap the device has to fill in before the program can run (products the host would take seconds for)
+struct TabulateTodo {
+    std::vector<int32_t> key;     // table_cache key
+    int32_t tables_off = 0;       // where its words sit in FlatProgram::tables
+    long long product = 0;
+    int32_t code_off = 0, code_len = 0, uses_valid = 0;
+    std::vector<int32_t> scope;   // variable ids, scope order (= stride order)
+};
+
 struct FlatProgram {
+    std::vector<TabulateTodo> todo;
     std::vector<SetDesc> sets;
     std::vector<ConDesc> cons;
     std::vector<int32_t> scope, code, firstvars, transvals;
@@ -66,6 +87,9 @@ public:
     std::vector<int> sig_vars, until_x, until_y;
     std::vector<std::unique_ptr<HostSet>> sets;
     std::string error;
+    std::map<std::vector<int32_t>, TableEntry> table_cache;
+    bool device_tabulation = false;  // products in (kBitmapMaxBits, kBitmapMaxBitsDevice] become bitmaps filled in by the device
+    void store_tabulated(const std::vector<int32_t> &key, const uint32_t *words, size_t n, long long product);
 
     int init(const stcsp_problem *p, bool sharded_tags);
     // next set for a leaf of `set` whose first-variables have the given values (in
@@ -89,7 +113,7 @@ private:
     Tree *translate(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
     Tree *translate_first(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
     int eval_tree(const Tree *t, const std::vector<int> &scope, const int *vals, bool &valid) const;
-    void build_tables(const HostCon &c, ConDesc &cd, FlatProgram &out, std::vector<ItemDesc> &small, bool &is_small);
+    void build_entry(const HostCon &c, TableEntry &e);
     int compile_expr(const Tree *t, const std::vector<int> &scope, bool guards, std::vector<int32_t> &code, int &depth,
                      int &max_depth, int &mask_depth);
 };

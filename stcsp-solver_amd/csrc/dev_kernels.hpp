@@ -856,6 +856,100 @@ __global__ __launch_bounds__(256) void k_adopt(Ctx c, const uint32_t *recs, long
     for (int k = lane; k < c.NK; k += 64) dst[4 + k] = rec[kXferHdr + k];
 }
 
+// ------------------------------------------------------------------ k_tabulate
+// Tuple bitmap of one point constraint, filled in on the device: one THREAD per tuple of the full initial
+// product (mixed radix over the scope, first variable fastest -- the stride order of ConDesc::stride_off), each
+// running the constraint's postfix program with the semantics of solverValidateRe (reference
+// src/solveralgorithm.cpp:336-424; the same interpreter as eval_program, scalar, stack in registers/scratch). The
+// host tabulates products up to kBitmapMaxBits (~0.1 us per tuple); an 8-ary constraint over 11-value domains has
+// 35 M tuples -- seconds on the host, about a millisecond here -- and without its bitmap every revision of it
+// interprets the program block by block (digitinvader9: 88 % of all revision cycles).
+struct TabArgs {
+    const int *code;       // the program
+    const int *arr_off;    // array table (offsets / data)
+    const int *arr_data;
+    long long product;
+    int scope_len, uses_valid;
+    int size[kMaxScope > 16 ? 16 : kMaxScope];  // (constraints over more than 16 variables are never tabulated: 2^16 < product)
+    int lb[16];
+};
+__global__ __launch_bounds__(256) void k_tabulate(TabArgs a, uint32_t *bitmap) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    int vals[16];
+    {
+        uint32_t rem = t < a.product ? (uint32_t)t : 0u;  // product <= kBitmapMaxBitsDevice = 2^28
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < a.scope_len) {
+                const uint32_t q = rem / (uint32_t)a.size[j];
+                vals[j] = a.lb[j] + (int)(rem - q * (uint32_t)a.size[j]);
+                rem = q;
+            }
+    }
+    int stk[32];
+    int sp = 0, tos = 0;
+    bool valid = true;
+    uint32_t dead = 0;
+    for (int pc = 0;;) {
+        const int w = a.code[pc++], op = w & 255, arg = w >> 8;
+        if (op == OP_END) break;
+        switch (op) {
+            case OP_CONST: stk[sp++ & 31] = tos; tos = a.code[pc++]; break;
+            case OP_VAR: stk[sp++ & 31] = tos; tos = vals[arg & 15]; break;
+            case OP_ARR: {
+                const int off = a.arr_off[arg], size = a.arr_off[arg + 1] - off;
+                const bool inr = (unsigned)tos < (unsigned)size;
+                if (!inr && dead == 0) valid = false;
+                tos = inr ? a.arr_data[off + tos] : 0;
+                break;
+            }
+            case OP_ABS: tos = tos < 0 ? (int)(0u - (unsigned)tos) : tos; break;
+            case OP_NOT: tos = (tos == 0); break;
+            case OP_MASK_T:
+            case OP_MASK_F: {
+                const int v = arg == 0 ? tos : stk[(sp - arg) & 31];
+                const bool live = (op == OP_MASK_T) ? (v != 0) : (v == 0);
+                dead = (dead << 1) | (live ? 0u : 1u);
+                break;
+            }
+            case OP_MASK_POP: dead >>= 1; break;
+            case OP_SEL_IF: {
+                const int b = tos, x = stk[(sp - 1) & 31], cnd = stk[(sp - 2) & 31];
+                sp -= 2;
+                tos = cnd ? x : b;
+                break;
+            }
+            case OP_SEL_AND: { const int x = stk[--sp & 31]; tos = x ? tos : 0; break; }
+            case OP_SEL_OR: { const int x = stk[--sp & 31]; tos = x ? 1 : tos; break; }
+            case OP_SEL_IMPLY: { const int x = stk[--sp & 31]; tos = (x == 0) ? 1 : (x <= tos); break; }
+            default: {
+                const int b = tos, x = stk[--sp & 31];
+                int r = 0;
+                switch (op) {
+                    case OP_ADD: r = (int)((unsigned)x + (unsigned)b); break;
+                    case OP_SUB: r = (int)((unsigned)x - (unsigned)b); break;
+                    case OP_MUL: r = (int)((unsigned)x * (unsigned)b); break;
+                    case OP_DIV: r = (b == 0 || (x == INT_MIN && b == -1)) ? 0 : x / b; break;
+                    case OP_MOD: r = (b == 0 || (x == INT_MIN && b == -1)) ? 0 : x % b; break;
+                    case OP_LT: r = x < b; break;
+                    case OP_GT: r = x > b; break;
+                    case OP_LE: r = x <= b; break;
+                    case OP_GE: r = x >= b; break;
+                    case OP_EQ: r = x == b; break;
+                    case OP_NE: r = x != b; break;
+                    default: break;
+                }
+                tos = (a.uses_valid && !valid) ? 0 : r;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(t < a.product && tos != 0);
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (t - lane) >> 5;  // the wavefront's two bitmap words
+    if (lane == 0 && t - lane < a.product) bitmap[w0] = (uint32_t)m;
+    if (lane == 32 && t - lane + 32 < a.product) bitmap[w0 + 1] = (uint32_t)(m >> 32);
+}
+
 // re-insert every state into a larger table
 __global__ void k_rehash(Ctx c, uint32_t n_states) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -12,12 +12,13 @@ namespace dev {
 constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
-constexpr int kStatWords = 36;
+constexpr int kStatWords = 44;
 enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
        ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
        ST_QPUSH, ST_QPOP, ST_POLLS, ST_IDLE_CYC, ST_BUSY_CYC, ST_PSTACK_POP, ST_WAVES_WORKED,
        ST_CYC_STAGE, ST_BLOCKS, ST_CYC_FINAL, ST_ROUNDS_FINAL, ST_CYC_BLOCK,
-       ST_CYC_RV_SETUP, ST_CYC_RV_LOOP, ST_CYC_RV_WB, ST_CYC_CLOSE, ST_CYC_LEAF, ST_RV_BLOCKS, ST_RV_OPEN, ST_RV_LANES };
+       ST_CYC_RV_SETUP, ST_CYC_RV_LOOP, ST_CYC_RV_WB, ST_CYC_CLOSE, ST_CYC_LEAF, ST_RV_BLOCKS, ST_RV_OPEN, ST_RV_LANES,
+       ST_CYC_RV_DIGITS, ST_CYC_RV_EVAL_BITMAP, ST_CYC_RV_EVAL_CODE, ST_CYC_RV_SUPPORT, ST_RV_BLOCKS_CODE };
 // per-wavefront LDS words behind the block copy: [0] rows examined by the current node's sweeps, [1 + ST_x]
 // the wavefront's work counters of this launch (flushed to the global statistics once per launch)
 constexpr int kLdsStatWords = 12;

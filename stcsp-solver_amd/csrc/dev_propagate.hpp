@@ -109,6 +109,8 @@ struct Dom {
 struct WaveStats {  // STCSP_PHASES build only: cycle shares of one node
     unsigned long long cyc_sweep = 0, cyc_wave = 0, cyc_rv_setup = 0, cyc_rv_loop = 0, cyc_rv_wb = 0, cyc_close = 0;
     unsigned rv_blocks = 0, rv_open = 0, rv_lanes = 0;  // blocks, open variables, tuple lanes of the general revisions
+    unsigned long long cyc_rv_digits = 0, cyc_rv_eval_bitmap = 0, cyc_rv_eval_code = 0, cyc_rv_support = 0;
+    unsigned rv_blocks_code = 0;
 };
 
 // What a wavefront keeps across the nodes it expands in one launch:
@@ -142,7 +144,28 @@ struct WaveEnv {
 template <bool L>
 __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc0, int code_len, bool uses_valid, int lane, uint32_t varinfo, int curval,
                             const int *lds_vals, int *lds_stk) {
-    int t = 0, sp = 0;
+    // Operand stack: the top in `t`, the three entries below it in registers (s1 = most recent), anything deeper in
+    // LDS -- expressions rarely nest deeper, so a push / pop is a few register moves instead of an LDS round trip
+    // per instruction (a dependent ds_read is ~100 cycles, and an instruction used to cost ~350).
+    int t = 0, s1 = 0, s2 = 0, s3 = 0, sp = 0;  // sp = entries below t
+    auto push = [&]() {  // push t (the caller then sets the new top)
+        if (sp >= 3) lds_stk[(sp - 3) * 64 + lane] = s3;
+        s3 = s2;
+        s2 = s1;
+        s1 = t;
+        sp++;
+    };
+    auto pop = [&]() -> int {  // the entry below t
+        const int x = s1;
+        s1 = s2;
+        s2 = s3;
+        if (sp > 3) s3 = lds_stk[(sp - 4) * 64 + lane];
+        sp--;
+        return x;
+    };
+    auto peek = [&](int d) -> int {  // d entries below t (d >= 1)
+        return d == 1 ? s1 : (d == 2 ? s2 : (d == 3 ? s3 : lds_stk[(sp - d) * 64 + lane]));
+    };
     bool valid = true;
     uint32_t dead = 0;
     // The program itself lives in two VGPRs for the duration of the call (word k in lane k): fetching an
@@ -161,13 +184,11 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc0, int code_len
         switch (op) {
             case OP_END: return t;
             case OP_CONST:
-                lds_stk[sp * 64 + lane] = t;
-                sp++;
+                push();
                 t = fetch(pc++);
                 break;
             case OP_VAR: {
-                lds_stk[sp * 64 + lane] = t;
-                sp++;
+                push();
                 uint32_t info = rdlane(varinfo, arg);
                 if (info)
                     t = lds_vals[(info - 1) * 64 + lane];
@@ -186,35 +207,35 @@ __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc0, int code_len
             case OP_NOT: t = (t == 0); break;
             case OP_MASK_T:
             case OP_MASK_F: {
-                int v = arg == 0 ? t : lds_stk[(sp - arg) * 64 + lane];
+                int v = arg == 0 ? t : peek(arg);
                 bool live = (op == OP_MASK_T) ? (v != 0) : (v == 0);
                 dead = (dead << 1) | (live ? 0u : 1u);
                 break;
             }
             case OP_MASK_POP: dead >>= 1; break;
             case OP_SEL_IF: {
-                int b = t, a = lds_stk[(sp - 1) * 64 + lane], cnd = lds_stk[(sp - 2) * 64 + lane];
-                sp -= 2;
+                const int b = t, a = pop(), cnd = pop();
                 t = cnd ? a : b;
                 break;
             }
             case OP_SEL_AND: {
-                int a = lds_stk[--sp * 64 + lane];
+                const int a = pop();
                 t = a ? t : 0;
                 break;
             }
             case OP_SEL_OR: {
-                int a = lds_stk[--sp * 64 + lane];
+                const int a = pop();
                 t = a ? 1 : t;
                 break;
             }
             case OP_SEL_IMPLY: {
-                int a = lds_stk[--sp * 64 + lane];
+                const int a = pop();
                 t = (a == 0) ? 1 : (a <= t);
                 break;
             }
             default: {
-                int b = t, a = lds_stk[--sp * 64 + lane], r = 0;
+                const int b = t, a = pop();
+                int r = 0;
                 switch (op) {
                     case OP_ADD: r = (int)((unsigned)a + (unsigned)b); break;
                     case OP_SUB: r = (int)((unsigned)a - (unsigned)b); break;
@@ -391,98 +412,169 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, cons
     }
     const int vlb = lane < s ? G.v(c.o.var_lb + var) : 0;
 
-    // --- general revision: enumerate the product of the OPEN (non-singleton) scope variables, 64 tuples per
-    // block (tuple index = block * 64 + lane, decomposed in mixed radix over the open variables in scope
-    // order), evaluate every tuple (bitmap look-up or postfix program), and OR the value bits of the
-    // satisfying tuples into per-variable support sets. Singletons are constants. One short scalar loop over
-    // the open variables per block: no lane/odometer split, no per-(variable, digit) lanes.
+    // --- general revision: enumerate the product of the OPEN (non-singleton) scope variables, evaluate every
+    // tuple (bitmap look-up or postfix program) and collect, per variable, the values that occur in a satisfying
+    // tuple. The open variables are split: "low" ones, whose domain sizes multiply to <= 64, are enumerated
+    // ACROSS LANES (lane = mixed-radix tuple index; the digits are worked out once per revision), the rest
+    // ("high") are stepped wave-uniformly by an odometer, one block of <= 64 tuples per step. Singletons are
+    // constants. Most revisions have no high variable: one block.
     const unsigned long long openm = __ballot(lane < s && n > 1);
-    const int nopen = __popcll(openm);
-    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the product is
-    // larger than the budget the revision could never finish, so it is skipped outright. This keeps
+    // Tuple bitmaps: scope variable 0 (stride 1: normally the X of `X == ...`) is NEVER enumerated. The bits of all its
+    // values for one tuple of the OTHER variables are contiguous, so one (possibly straddling) 32-bit window of the
+    // bitmap ANDed with its domain says at once whether that tuple has a support and which values of variable 0 it
+    // supports: the product shrinks by |D(variable 0)| (11-fold for the `next D == if ...` constraints of digitinvader).
+    const unsigned long long enumm = use_bitmap ? (openm & ~1ull) : openm;
+    const uint32_t D0 = rdlane(D, 0);
+    unsigned long long lowmask = 0, highmask = 0;
+    int Plow = 1, nlow = 0;
+    unsigned long long nsteps = 1;  // odometer range = product of the high domain sizes
+    // Budget. Pruning a value needs the WHOLE product of the other variables refuted; when the odometer range
+    // is larger than the budget the revision could never finish, so it is skipped outright. This keeps
     // propagation sound (no value is ever removed without proof) and the search complete: at a leaf every
     // variable is a singleton, the product is 1 and the constraint is checked exactly -- the same argument that
-    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield the same
-    // automaton. A lane keeps the value bits of its tuple packed in 64 bits (5 per open variable: at most
-    // kMaxOpenVars); the interpreter additionally needs the tuple values in LDS (at most kMaxLowVars).
-    unsigned long long P = 1;
-    {
-        const unsigned long long budget = 64ull * (unsigned long long)(unsigned)(use_bitmap ? c.budget_bitmap : c.budget_code);
-        for (unsigned long long m = openm; m && P <= budget; m &= m - 1) P *= (unsigned long long)rdlane((uint32_t)n, __ffsll((long long)m) - 1);
-        if (P > budget || nopen > kMaxOpenVars || (!use_bitmap && nopen > kMaxLowVars)) {
-            if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
-            S.n_skipped++;
-            return true;
+    // makes the reference's weaker, bounds-only propagation (solveralgorithm.cpp:476-523) yield the same automaton.
+    const unsigned long long budget = (unsigned long long)(unsigned)(use_bitmap ? c.budget_bitmap : c.budget_code);
+    for (unsigned long long m = enumm; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const int nj = (int)rdlane((uint32_t)n, j);
+        if (nlow < kMaxLowVars && Plow * nj <= 64) {
+            lowmask |= 1ull << j;
+            Plow *= nj;
+            nlow++;
+        } else {
+            highmask |= 1ull << j;
+            if (nsteps <= budget) nsteps *= (unsigned long long)nj;
         }
+    }
+    if (nsteps > budget) {
+        if (lane == (item >> 5)) dirtyw &= ~(1u << (item & 31));
+        S.n_skipped++;
+        return true;
     }
     const unsigned long long t_rv1 = PHASE_NOW();
     (void)t_rv1;
-    // exact x / n for n <= 32, x < 2^27: mulhi(x, ceil(2^32 / n)) (device_types.hpp kDivMagic, in the image)
-    const uint32_t magic = lane < s ? (uint32_t)G.v(c.o.divmagic + n) : 0u;
-    const int curbit0 = lane < s ? (__ffs((int)D) - 1) : 0;
-    const int curval = vlb + curbit0;  // singletons: their value; open variables: unused
-    // scope lane j of an open variable: 1 + its slot in lds_vals (ascending scope order)
-    const uint32_t varinfo = (lane < s && n > 1) ? 1u + (uint32_t)__popcll(openm & ((1ull << lane) - 1ull)) : 0u;
+    // low variables: this lane's digit / value bit of each (once), packed 5 bits per variable
+    const bool active = lane < Plow;
+    int lane_part = 0;     // bitmap index contribution of the low variables
+    uint32_t pack = 0;     // value bit of low variable `slot` in bits [5 slot, 5 slot + 5)  (kMaxLowVars <= 6)
+    {
+        int Pj = 1, slot = 0;
+        for (unsigned long long m = lowmask; m; m &= m - 1, slot++) {
+            const int j = __ffsll((long long)m) - 1;
+            const int nj = (int)rdlane((uint32_t)n, j);
+            const uint32_t Dj = rdlane(D, j);
+            // Pj, nj, Dj are wave-uniform: powers of two divide by shifting; lane < 64 divides exactly through one reciprocal
+            const int q = (Pj & (Pj - 1)) == 0 ? (lane >> (__ffs(Pj) - 1)) : small_div(lane, Pj);
+            const int digit = (nj & (nj - 1)) == 0 ? (q & (nj - 1)) : q - nj * small_div(q, nj);
+            int bitpos = 0;
+            if (nj <= 4) {
+                int k = 0;
+                for (uint32_t mm = Dj; mm; mm &= mm - 1, k++) bitpos = digit == k ? __ffs((int)mm) - 1 : bitpos;
+            } else {
+                bitpos = select_kth_fast(Dj, digit);
+            }
+            pack |= (uint32_t)bitpos << (5 * slot);
+            if (use_bitmap)
+                lane_part += bitpos * (int)rdlane((uint32_t)mystride, j);
+            else
+                lds_vals[slot * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
+            Pj *= nj;
+        }
+    }
+    // scope lane j: 1 + slot for a low variable (the interpreter reads its value from lds_vals), 0 otherwise
+    const uint32_t varinfo = ((lowmask >> lane) & 1ull) ? 1u + (uint32_t)__popcll(lowmask & ((1ull << lane) - 1ull)) : 0u;
+    const bool is_high = (highmask >> lane) & 1ull;
+    int curbit = lane < s ? (__ffs((int)D) - 1) : 0;  // singletons: their bit; high variables: the odometer's current bit
+    int curval = vlb + curbit;
+    int digit_h = 0;
     int base_sum = 0;  // bitmap index contribution of the singletons
-    if (use_bitmap) base_sum = wave_sum((lane < s && n == 1) ? curbit0 * mystride : 0);
+    if (use_bitmap) base_sum = wave_sum((lane >= 1 && lane < s && n == 1) ? curbit * mystride : 0);  // (variable 0: the window)
+    uint32_t acc0 = 0;  // tuple lanes: values of variable 0 this lane's tuples support
     S.n_revs++;
     S.n_wave_revs++;
 #ifdef STCSP_PHASES
-    ws.rv_open += (unsigned)nopen;
-    ws.rv_lanes += (unsigned)(P < 64 ? P : 64);
+    ws.rv_open += (unsigned)__popcll(openm);
+    ws.rv_lanes += (unsigned)Plow;
 #endif
-    uint32_t hs = 0;  // scope lanes of open variables: supported value bits so far
+    uint32_t hs = 0;      // scope lanes of high variables: supported value bits so far
+    bool satany = false;  // tuple lanes: this low tuple was satisfied in some block
     bool any_sat = false;
-    const unsigned nblocks = (unsigned)((P + 63) >> 6);
-    // blocks are visited in a scattered order (b * odd stride mod 2^k, skipping the overshoot) so that the digits
-    // of the slow (high-stride) variables vary early: loose constraints are fully supported after a few blocks
-    unsigned nb2 = 1;
-    while (nb2 < nblocks) nb2 <<= 1;
-    const unsigned bstride = (nb2 >> 1) | (nb2 >> 3) | 1u;  // odd: a full cycle modulo nb2
-    unsigned visited = 0;
-    for (unsigned step = 0; step < nb2 && visited < nblocks; step++) {
-        const unsigned blk = (step * bstride) & (nb2 - 1);
-        if (blk >= nblocks) continue;
-        visited++;
-        const unsigned t = blk * 64u + (unsigned)lane;
-        const bool active = (unsigned long long)t < P;
-        unsigned rem = active ? t : 0u;
-        int bit = base_sum, slot = 0;
-        unsigned long long pack = 0;  // value bit of open variable `slot` in bits [5 slot, 5 slot + 5)
-        for (unsigned long long m = openm; m; m &= m - 1, slot++) {
-            const int j = __ffsll((long long)m) - 1;
-            const uint32_t nj = rdlane((uint32_t)n, j), Dj = rdlane(D, j);
-            const unsigned q = __umulhi(rem, rdlane(magic, j));
-            const int digit = (int)(rem - q * nj);
-            rem = q;
-            const int bitpos = select_kth_fast(Dj, digit);
-            pack |= (unsigned long long)(unsigned)bitpos << (5 * slot);
-            if (use_bitmap)
-                bit += bitpos * (int)rdlane((uint32_t)mystride, j);
-            else
-                lds_vals[slot * 64 + lane] = (int)rdlane((uint32_t)vlb, j) + bitpos;
-        }
+    for (unsigned long long step = 0;; step++) {
+        const unsigned long long t_b1 = PHASE_NOW();
+        (void)t_b1;
         int res;
-        if (use_bitmap)
-            res = active ? (int)(((uint32_t)G.vc(c.o.tables + C.bitmap_off + (bit >> 5)) >> (bit & 31)) & 1u) : 0;
-        else
+        if (use_bitmap) {
+            int bit = lane_part + base_sum;
+            for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+                const int j = __ffsll((long long)hm) - 1;
+                bit += (int)rdlane((uint32_t)curbit, j) * (int)rdlane((uint32_t)mystride, j);
+            }
+            // window of variable 0's bits at this tuple of the others (second word only when the domain reaches into it)
+            const int tw = c.o.tables + C.bitmap_off + (bit >> 5), sh = bit & 31;
+            const uint32_t wlo = active ? (uint32_t)G.vc(tw) : 0u;
+            const uint32_t whi = (active && sh + (31 - __clz((int)D0)) >= 32) ? (uint32_t)G.vc(tw + 1) : 0u;
+            const uint32_t sup0 = (uint32_t)((((unsigned long long)whi << 32) | wlo) >> sh) & D0;
+            acc0 |= sup0;
+            res = sup0 != 0;
+        } else {
             res = eval_program<L>(c, G, C.code_off, C.code_len, C.uses_valid != 0, lane, varinfo, curval, lds_vals, lds_stk);
-        S.n_evals += (unsigned)(P - (unsigned long long)blk * 64u < 64 ? P - (unsigned long long)blk * 64u : 64);
+        }
+        S.n_evals += (unsigned)Plow;
+        const bool sat = active && res != 0;
+        const unsigned long long sm = __ballot(sat);
 #ifdef STCSP_PHASES
         ws.rv_blocks++;
+        const unsigned long long t_b2 = PHASE_NOW();
+        (use_bitmap ? ws.cyc_rv_eval_bitmap : ws.cyc_rv_eval_code) += t_b2 - t_b1;
+        if (!use_bitmap) ws.rv_blocks_code++;
 #endif
-        const bool sat = active && res != 0;
-        if (__ballot(sat)) {
+        if (sm) {
             any_sat = true;
-            slot = 0;
-            for (unsigned long long m = openm; m; m &= m - 1, slot++) {
-                const int j = __ffsll((long long)m) - 1;
-                const int bitpos = (int)(pack >> (5 * slot)) & 31;
-                const uint32_t got = wave_or32(sat ? 1u << bitpos : 0u);
-                if (lane == j) hs |= got;
-            }
-            if (__ballot(((openm >> lane) & 1ull) && hs != D) == 0) break;  // everything is supported
+            satany = satany || sat;
+            if (is_high) hs |= 1u << curbit;
         }
+        if (!highmask) break;  // the lanes covered the whole product
+        // everything supported already? (every low tuple satisfied at least once, every high value seen, all of variable 0)
+        if (__ballot((active && !satany) || (is_high && hs != D)) == 0 && (!use_bitmap || wave_or32(acc0) == D0)) break;
+        // advance the odometer (wave-uniform carry chain over the high variables)
+        bool carry = true;
+        for (unsigned long long hm = highmask; hm && carry; hm &= hm - 1) {
+            const int j = __ffsll((long long)hm) - 1;
+            int dj = (int)rdlane((uint32_t)digit_h, j) + 1;
+            const int nj = (int)rdlane((uint32_t)n, j);
+            if (dj == nj)
+                dj = 0;
+            else
+                carry = false;
+            if (lane == j) {
+                digit_h = dj;
+                curbit = select_kth_fast(D, dj);
+                curval = vlb + curbit;
+            }
+        }
+        if (carry) break;  // wrapped around: product exhausted
+        if (step > (1ull << 22)) {
+            S.err = max(S.err, (unsigned)ERR_WATCHDOG);
+            return false;
+        }
+    }
+    // supported values of the low variables: the value bits of the lanes whose tuple was satisfied
+    {
+        const unsigned long long t_s = PHASE_NOW();
+        (void)t_s;
+        int slot = 0;
+        for (unsigned long long m = lowmask; m; m &= m - 1, slot++) {
+            const int j = __ffsll((long long)m) - 1;
+            const uint32_t got = wave_or32(satany ? 1u << ((pack >> (5 * slot)) & 31u) : 0u);
+            if (lane == j) hs = got;
+        }
+        if (use_bitmap) {  // variable 0: the union of the windows
+            const uint32_t got0 = wave_or32(acc0);
+            if (lane == 0) hs = got0;
+        }
+#ifdef STCSP_PHASES
+        ws.cyc_rv_support += PHASE_NOW() - t_s;
+#endif
     }
     const unsigned long long t_rv2 = PHASE_NOW();
     (void)t_rv2;
@@ -957,6 +1049,11 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_RV_BLOCKS, ws.rv_blocks);
         add_stats(c, gw, ST_RV_OPEN, ws.rv_open);
         add_stats(c, gw, ST_RV_LANES, ws.rv_lanes);
+        add_stats(c, gw, ST_CYC_RV_DIGITS, ws.cyc_rv_digits);
+        add_stats(c, gw, ST_CYC_RV_EVAL_BITMAP, ws.cyc_rv_eval_bitmap);
+        add_stats(c, gw, ST_CYC_RV_EVAL_CODE, ws.cyc_rv_eval_code);
+        add_stats(c, gw, ST_CYC_RV_SUPPORT, ws.cyc_rv_support);
+        add_stats(c, gw, ST_RV_BLOCKS_CODE, ws.rv_blocks_code);
     }
 #endif
     if (!consistent) {

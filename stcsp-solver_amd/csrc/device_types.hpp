@@ -17,8 +17,7 @@ namespace stcsp {
 constexpr int kRegions = 32;        // cursor shards per segment (spreads allocation atomics)
 constexpr int kMaxDomRegs = 4;      // N*K <= 64 * kMaxDomRegs words live in VGPRs, lane-striped
 constexpr int kCompactSweepItems = 128;  // sets with more small items than this sweep over a compacted dirty list
-constexpr int kMaxLowVars = 8;      // open scope variables of an INTERPRETED constraint one revision enumerates (tuple values in LDS)
-constexpr int kMaxOpenVars = 12;    // open scope variables of any general revision (value bits packed 5 x 12 in a register pair)
+constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revision (2^6 = 64; value bits packed 5 x 6 in a register)
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
@@ -26,7 +25,8 @@ constexpr unsigned long long kBudgetBitmapIters = 4096;  // odometer steps a bit
 constexpr unsigned long long kBudgetCodeIters = 32;      // ... and an interpreted one
 constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
-constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap compiled per constraint
+constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap the HOST tabulates per constraint (~0.1 us per tuple)
+constexpr long long kBitmapMaxBitsDevice = 1ll << 28;  // ... and the largest one at all: bigger ones up to here are tabulated on the device
 
 enum ConType : int32_t { CT_NEXT = 0, CT_POINT = 1, CT_UNTIL = 2, CT_AT = 3 };
 

@@ -105,7 +105,7 @@ struct stcsp_engine {
     int chain_small = 4, chain_big = 2, chain_thresh = 4096, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
-    DevBuf<int> d_arr_data, d_code, d_miss;
+    DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss;
     DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
     bool img_in_lds = false;
     DevBuf<unsigned long long> d_slots, d_stats;
@@ -275,6 +275,31 @@ struct stcsp_engine {
         o.words = (int)img.size();
         HIPCHK(d_img.upload(img));
         HIPCHK(d_code.upload(prog.code));
+        // bitmaps too big for the host to tabulate: the device fills them in (k_tabulate), once -- the result goes
+        // back into the SetManager's table cache, so later compiles place the finished words
+        for (const TabulateTodo &td : prog.todo) {
+            if (td.scope.size() > 16) return fail(STCSP_E_INTERNAL, "device tabulation of a %zu-ary constraint", td.scope.size());
+            TabArgs ta{};
+            ta.code = d_code.p + td.code_off;
+            ta.product = td.product;
+            ta.scope_len = (int)td.scope.size();
+            ta.uses_valid = td.uses_valid;
+            for (size_t j = 0; j < td.scope.size(); j++) {
+                ta.size[j] = mgr.ub[td.scope[j]] - mgr.lb[td.scope[j]] + 1;
+                ta.lb[j] = mgr.lb[td.scope[j]];
+            }
+            if (!d_arr_off.p) HIPCHK(d_arr_off.upload(mgr.array_off));
+            ta.arr_off = d_arr_off.p;
+            ta.arr_data = d_arr_data.p;
+            uint32_t *dst = d_img.p + o.tables + td.tables_off;
+            const size_t nwords = (size_t)((td.product + 31) / 32);
+            hipLaunchKernelGGL(k_tabulate, dim3((unsigned)((td.product + 255) / 256)), dim3(256), 0, stream, ta, dst);
+            HIPCHK(hipGetLastError());
+            std::vector<uint32_t> back(nwords);
+            HIPCHK(hipMemcpyAsync(back.data(), dst, nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            mgr.store_tabulated(td.key, back.data(), nwords, td.product);
+        }
         ctx.img = d_img.p;
         ctx.o = o;
         ctx.code = d_code.p;
@@ -333,6 +358,11 @@ struct stcsp_engine {
             if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
                 max_blocks = per_cu * prop.multiProcessorCount;
             if (const char *ev = getenv("STCSP_BLOCKS")) if (atoi(ev) > 0) max_blocks = atoi(ev);
+            if (getenv("STCSP_DEBUG")) {
+                fprintf(stderr, "[engine] staging cuts (words):");
+                for (int cut : hot_end) fprintf(stderr, " %d", cut);
+                fprintf(stderr, "\n");
+            }
             if (getenv("STCSP_DEBUG"))
                 fprintf(stderr, "[engine] %s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
                         lite ? "LITE" : "general", o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
@@ -347,6 +377,7 @@ struct stcsp_engine {
         sharded = opt.world > 1 || (opt.flags & STCSP_F_STEPPED) != 0;
         int rc = mgr.init(p, sharded);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
+        mgr.device_tabulation = !(getenv("STCSP_DEVICE_TABULATE") && atoi(getenv("STCSP_DEVICE_TABULATE")) == 0);
         const int N = mgr.N, K = mgr.K;
         for (int v = 0; v < N; v++) {
             long long width = (long long)mgr.ub[v] - (long long)mgr.lb[v] + 1;
@@ -875,6 +906,13 @@ struct stcsp_engine {
                     (double)tot[ST_RV_BLOCKS] / std::max(1.0, (double)tot[ST_RV_LANES] > 0 ? (double)tot[ST_CYC_RV_SETUP] > 0 ? (double)tot[ST_WAVEREVS] : 1.0 : 1.0),
                     (double)tot[ST_RV_OPEN] / std::max(1.0, (double)tot[ST_WAVEREVS]), (double)tot[ST_RV_LANES] / std::max(1.0, (double)tot[ST_WAVEREVS]),
                     (double)tot[ST_WAVEREVS] / tot[ST_NODES]);
+        if (tot[ST_RV_BLOCKS])
+            fprintf(stderr, "[phases] per tuple block: digits %.0f cycles; evaluation: bitmap %.0f (x %llu blocks), bytecode %.0f (x %llu blocks); support sets %.0f\n",
+                    (double)tot[ST_CYC_RV_DIGITS] / tot[ST_RV_BLOCKS],
+                    (double)tot[ST_CYC_RV_EVAL_BITMAP] / std::max<double>(1.0, (double)(tot[ST_RV_BLOCKS] - tot[ST_RV_BLOCKS_CODE])),
+                    (unsigned long long)(tot[ST_RV_BLOCKS] - tot[ST_RV_BLOCKS_CODE]),
+                    (double)tot[ST_CYC_RV_EVAL_CODE] / std::max<double>(1.0, (double)tot[ST_RV_BLOCKS_CODE]), (unsigned long long)tot[ST_RV_BLOCKS_CODE],
+                    (double)tot[ST_CYC_RV_SUPPORT] / tot[ST_RV_BLOCKS]);
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: closures of the next arcs %.0f, leaf part of process_node (transition, signature, hash, time shift) %.0f\n",
                     (double)tot[ST_CYC_CLOSE] / tot[ST_NODES], (double)tot[ST_CYC_LEAF] / tot[ST_NODES]);

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-2 profiles: rocprofv3 kernel-trace stats + separate PMC passes (never combined with other trace
+# domains) for the headline workload (partialorder_14) and kernel-trace stats for digitinvader9 and the
+# synthetic 64 x 32 instance. Raw output under gpurun_out/prof_r02/; tools/profile_r02_summaries.py turns it
+# into the files committed under profiles/.
+set -e
+cd "$GRAFT_REPO_ROOT"
+R=$PWD
+export TMPDIR=/tmp
+OUT=$R/gpurun_out/prof_r02
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-other-workloads"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_p14 -- $B --steps 5 --warmup 2 > $OUT/stats_p14.json 2> $OUT/stats_p14.err
+echo "stats p14 done"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$name -- $B --steps 1 --warmup 0 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  echo "pass $name done"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_d9 -- $B --workload digitinvader9 --steps 3 --warmup 1 > $OUT/stats_d9.json 2> $OUT/stats_d9.err
+echo "stats d9 done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_d9 -- $B --workload digitinvader9 --steps 1 --warmup 0 > $OUT/pmc_d9.json 2> $OUT/pmc_d9.err
+echo "pmc d9 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_synth -- python3 $R/tools/synth_bench.py 2.0 > $OUT/stats_synth.json 2> $OUT/stats_synth.err
+echo "stats synth done"
+find $OUT -name "*_kernel_stats.csv" | head
