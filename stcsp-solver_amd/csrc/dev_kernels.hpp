@@ -365,6 +365,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
         p->open_total = open_total + total - taken0;
         p->rounds = rounds + 1;
     }
+    if (rl) p->edge_seen[lane] = (unsigned)edges_r;
     if (total > 0) {
         if (sp >= kMaxSegments) {
             if (lane == 0) {
@@ -1034,6 +1035,53 @@ __global__ __launch_bounds__(256) void k_post_compact(EdgeView v, const uint8_t 
     const int q64 = 64 / N, r64 = 64 % N;
     int r = lane / N, k = lane - r * N;
     int32_t *out = oval + (size_t)base * N;
+    for (int w = lane; w < total; w += 64) {
+        out[w] = (int32_t)v.edges[tab[wib][r] + 4 + k];
+        r += q64;
+        k += r64;
+        if (k >= N) {
+            k -= N;
+            r++;
+        }
+    }
+}
+
+// Streaming export: the edge records [from[r], from[r] + n[r]) of every region -- written by launches that have
+// completed -- are transposed into the structure-of-arrays result at positions base, base + 1, ... while the
+// search goes on (another stream); the host copies each chunk out as soon as it is staged. Whether an edge
+// survives the ok/fail fixpoint is only known at the end: if no state fails (the usual case) the streamed arrays
+// ARE the result, otherwise the engine falls back to the compacting export.
+struct StreamView {
+    const uint32_t *edges;
+    uint32_t edge_cap;
+    int ES, N;
+    uint32_t from[R];
+    uint32_t pref[R + 1];  // prefix sums of the per-region record counts of this chunk
+};
+__global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned long long base, long long *osrc, long long *odst, int32_t *oval) {
+    __shared__ unsigned long long tab[4][64];
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t e0 = e - (uint32_t)lane;
+    if (e0 >= v.pref[R]) return;
+    const bool in = e < v.pref[R];
+    if (in) {
+        int r = 0;
+#pragma unroll
+        for (int step = R / 2; step >= 1; step >>= 1)
+            if (e >= v.pref[r + step]) r += step;
+        const uint32_t *er = v.edges + ((size_t)r * v.edge_cap + v.from[r] + (e - v.pref[r])) * v.ES;
+        tab[wib][lane] = (unsigned long long)(er - v.edges);
+        osrc[base + e] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
+        odst[base + e] = (long long)er[2];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nrec = (int)min(64u, v.pref[R] - e0);
+    const int N = v.N, total = nrec * N;
+    const int q64 = 64 / N, r64 = 64 % N;
+    int r = lane / N, k = lane - r * N;
+    int32_t *out = oval + (size_t)(base + e0) * N;
     for (int w = lane; w < total; w += 64) {
         out[w] = (int32_t)v.edges[tab[wib][r] + 4 + k];
         r += q64;

@@ -64,6 +64,7 @@ struct Plan {
     int chain_small, chain_big, chain_thresh;  // policy: chain_small while a round has <= chain_thresh nodes
     int chain_heavy;                           // a slot stops chaining after this many cycles in one launch
     long long rounds, open_total;
+    unsigned edge_seen[R];  // edge-log cursors at the end of the last accounted round (the host streams the log out while the search runs)
     DevSegment stack[kMaxSegments];
 };
 enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };

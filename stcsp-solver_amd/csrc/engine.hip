@@ -180,6 +180,7 @@ struct stcsp_engine {
         if (h_keys) (void)hipHostFree(h_keys);
         if (h_fail) (void)hipHostFree(h_fail);
         if (h_miss) (void)hipHostFree(h_miss);
+        if (xstream) (void)hipStreamDestroy(xstream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -393,6 +394,7 @@ struct stcsp_engine {
         device = opt.device;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&stream));
+        HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
         L = CtlLayout(opt.world);
         ctx.N = N;
         ctx.K = K;
@@ -501,6 +503,7 @@ struct stcsp_engine {
     int alloc_edges(uint32_t cap) {
         DevBuf<uint32_t> nb;
         HIPCHK(nb.alloc((size_t)R * cap * ctx.ES));
+        if (xstream) HIPCHK(hipStreamSynchronize(xstream));  // (a streaming chunk may still read the old log)
         if (d_edges.p)
             for (int r = 0; r < R; r++)
                 if (edge_count[r])
@@ -593,6 +596,11 @@ struct stcsp_engine {
         n_states = 0;
         truncated = false;
         levels = 0;
+        if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+        streamed = 0;
+        for (int r = 0; r < R; r++) streamed_r[r] = 0;
+        streaming = !sharded && !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
+                    !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         translation_stops = 0;
         finished = false;
         exp_on_device = false;
@@ -747,6 +755,93 @@ struct stcsp_engine {
         return STCSP_OK;
     }
 
+    // ---- streaming export (unsharded solves that will be exported): the edge log is transposed into the result
+    // arrays and copied to the host chunk by chunk on a second stream WHILE the search runs (the copy of
+    // partialorder_14's 95 MB is 1.7 ms at PCIe speed: more than a third of its whole solve when done afterwards)
+    hipStream_t xstream = nullptr;
+    bool streaming = false;
+    size_t streamed = 0;                 // edge records staged so far
+    uint32_t streamed_r[R] = {0};        // ... per region of the edge log
+    size_t stream_chunk_min = 32768;     // records per chunk (except the last)
+    int ensure_export_capacity(size_t E) {
+        const int N = ctx.N;
+        if (d_osrc.n < E) {
+            const size_t cap = std::max(E + E / 4 + 256, d_osrc.n * 2);
+            DevBuf<long long> ns, nd;
+            DevBuf<int32_t> nv;
+            HIPCHK(ns.alloc(cap));
+            HIPCHK(nd.alloc(cap));
+            HIPCHK(nv.alloc(cap * N));
+            if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+            if (streamed) {
+                HIPCHK(hipMemcpy(ns.p, d_osrc.p, streamed * sizeof(long long), hipMemcpyDeviceToDevice));
+                HIPCHK(hipMemcpy(nd.p, d_odst.p, streamed * sizeof(long long), hipMemcpyDeviceToDevice));
+                HIPCHK(hipMemcpy(nv.p, d_oval.p, streamed * N * sizeof(int32_t), hipMemcpyDeviceToDevice));
+            }
+            std::swap(d_osrc.p, ns.p);
+            std::swap(d_osrc.n, ns.n);
+            std::swap(d_odst.p, nd.p);
+            std::swap(d_odst.n, nd.n);
+            std::swap(d_oval.p, nv.p);
+            std::swap(d_oval.n, nv.n);
+        }
+        if (h_edge_cap < E) {
+            const size_t cap = std::max(E + E / 4 + 256, h_edge_cap * 2);
+            long long *ns = nullptr, *nd = nullptr;
+            int32_t *nv = nullptr;
+            HIPCHK(hipHostMalloc((void **)&ns, cap * sizeof(long long)));
+            HIPCHK(hipHostMalloc((void **)&nd, cap * sizeof(long long)));
+            HIPCHK(hipHostMalloc((void **)&nv, cap * N * sizeof(int32_t)));
+            if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+            if (streamed) {
+                memcpy(ns, h_osrc, streamed * sizeof(long long));
+                memcpy(nd, h_odst, streamed * sizeof(long long));
+                memcpy(nv, h_oval, streamed * N * sizeof(int32_t));
+            }
+            if (h_osrc) (void)hipHostFree(h_osrc);
+            if (h_odst) (void)hipHostFree(h_odst);
+            if (h_oval) (void)hipHostFree(h_oval);
+            h_osrc = ns;
+            h_odst = nd;
+            h_oval = nv;
+            h_edge_cap = cap;
+        }
+        return STCSP_OK;
+    }
+    // Stage and ship the edge records logged since the last call. `upto[r]` = cursor of region r as of the last
+    // COMPLETED launch (the main stream is synchronised at every call site).
+    int stream_edges(const uint32_t *upto, bool final) {
+        if (!streaming) return STCSP_OK;
+        StreamView v{};
+        size_t M = 0;
+        for (int r = 0; r < R; r++) {
+            v.from[r] = streamed_r[r];
+            v.pref[r] = (uint32_t)M;
+            M += upto[r] - streamed_r[r];
+        }
+        v.pref[R] = (uint32_t)M;
+        if (M == 0 || (!final && M < stream_chunk_min)) return STCSP_OK;
+        if (streamed + M > 0xfffffff0ull) {  // beyond the 32-bit record indices of the export kernels: compacting path decides
+            streaming = false;
+            return STCSP_OK;
+        }
+        int rc = ensure_export_capacity(streamed + M);
+        if (rc != STCSP_OK) return rc;
+        v.edges = d_edges.p;
+        v.edge_cap = ctx.edge_cap;
+        v.ES = ctx.ES;
+        v.N = ctx.N;
+        const int N = ctx.N;
+        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xstream, v, (unsigned long long)streamed, d_osrc.p, d_odst.p, d_oval.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
+        HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
+        HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xstream));
+        for (int r = 0; r < R; r++) streamed_r[r] = upto[r];
+        streamed += M;
+        return STCSP_OK;
+    }
+
     long long translation_stops = 0;
     int service_misses() {
         uint32_t nm = h_ctl[L.misc0 + MISC_NMISS * CST];
@@ -796,6 +891,7 @@ struct stcsp_engine {
             }
             rc = read_plan();
             if (rc != STCSP_OK) return rc;
+            if ((rc = stream_edges(h_plan->edge_seen, false))) return rc;
             if (dbg_rounds && burst == 1) {
                 std::vector<unsigned long long> st(kStatSlots * kStatWords);
                 HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1242,26 +1338,19 @@ struct stcsp_engine {
         v.pref[R] = (uint32_t)E;
         if (E > 0xfffffff0ull) return fail(STCSP_E_NOMEM, "edge log too large for the device export");
         if (d_alive.n < E) HIPCHK(d_alive.alloc(E + E / 4 + 256));
-        if (d_osrc.n < E) {
-            size_t cap = E + E / 4 + 256;
-            HIPCHK(d_osrc.alloc(cap));
-            HIPCHK(d_odst.alloc(cap));
-            HIPCHK(d_oval.alloc(cap * N));
+        if (streaming) {  // the rest of the log (the chunks before it left while the search ran)
+            int rcs = stream_edges(edge_count.data(), true);
+            if (rcs != STCSP_OK) return rcs;
+        }
+        {
+            int rcs = ensure_export_capacity(E);
+            if (rcs != STCSP_OK) return rcs;
         }
         if (d_fail.n < n_states) {
             HIPCHK(d_fail.alloc((size_t)n_states + n_states / 4 + 256));
             HIPCHK(d_outdeg.alloc((size_t)n_states + n_states / 4 + 256));
         }
         if (!d_post.p) HIPCHK(d_post.alloc(4));
-        if (h_edge_cap < E) {
-            if (h_osrc) (void)hipHostFree(h_osrc);
-            if (h_odst) (void)hipHostFree(h_odst);
-            if (h_oval) (void)hipHostFree(h_oval);
-            h_edge_cap = E + E / 4 + 256;
-            HIPCHK(hipHostMalloc((void **)&h_osrc, h_edge_cap * sizeof(long long)));
-            HIPCHK(hipHostMalloc((void **)&h_odst, h_edge_cap * sizeof(long long)));
-            HIPCHK(hipHostMalloc((void **)&h_oval, h_edge_cap * N * sizeof(int32_t)));
-        }
         if (h_state_cap < n_states) {
             if (h_keys) (void)hipHostFree(h_keys);
             if (h_fail) (void)hipHostFree(h_fail);
@@ -1286,25 +1375,35 @@ struct stcsp_engine {
         uint32_t live = 0;
         if (E) {
             hipLaunchKernelGGL(k_post_outdeg, dim3(eb), dim3(256), 0, stream, v, d_outdeg.p, d_alive.p);
+            bool streamed_is_final = false;
             for (int it = 0;; it++) {
                 hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
                 uint32_t changed = 0;
                 HIPCHK(hipMemcpyAsync(&changed, d_post.p, sizeof changed, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipStreamSynchronize(stream));
+                // nobody failed: every logged edge is kept, and the streamed arrays already hold them all
+                if (!changed && it == 0 && streaming && streamed == E) streamed_is_final = true;
                 if (!changed) break;
                 HIPCHK(hipMemsetAsync(d_post.p, 0, sizeof(uint32_t), stream));
                 hipLaunchKernelGGL(k_post_kill, dim3(eb), dim3(256), 0, stream, v, d_alive.p, (const uint8_t *)d_fail.p, d_outdeg.p);
                 if (it > (int)n_states + 8) return fail(STCSP_E_INTERNAL, "ok-fixpoint did not converge");
             }
             lap("fixpoint");
-            hipLaunchKernelGGL(k_post_compact, dim3(eb), dim3(256), 0, stream, v, (const uint8_t *)d_alive.p, d_post.p + 1, d_osrc.p, d_odst.p, d_oval.p);
-            HIPCHK(hipGetLastError());
-            lap("compact");
-            HIPCHK(hipMemcpyAsync(&live, d_post.p + 1, sizeof live, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            HIPCHK(hipMemcpyAsync(h_osrc, d_osrc.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_odst, d_odst.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_oval, d_oval.p, (size_t)live * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(xstream));  // the last streamed chunk has landed (or nothing was streamed)
+            if (streamed_is_final) {
+                live = (uint32_t)E;
+                lap("wait for the streamed chunks");
+            } else {
+                hipLaunchKernelGGL(k_post_compact, dim3(eb), dim3(256), 0, stream, v, (const uint8_t *)d_alive.p, d_post.p + 1, d_osrc.p, d_odst.p, d_oval.p);
+                HIPCHK(hipGetLastError());
+                lap("compact");
+                HIPCHK(hipMemcpyAsync(&live, d_post.p + 1, sizeof live, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                HIPCHK(hipMemcpyAsync(h_osrc, d_osrc.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(h_odst, d_odst.p, (size_t)live * sizeof(long long), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(h_oval, d_oval.p, (size_t)live * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                streaming = false;  // (the arrays no longer hold the streamed layout: a second export() compacts again)
+            }
         } else {
             // no edges at all: every non-root state is failed
             hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
