@@ -601,6 +601,7 @@ struct stcsp_engine {
         for (int r = 0; r < R; r++) streamed_r[r] = 0;
         streaming = !sharded && !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
+        if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
         translation_stops = 0;
         finished = false;
         exp_on_device = false;

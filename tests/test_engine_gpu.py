@@ -155,6 +155,38 @@ def test_engine_pool_growth_paths(stcsp, golden, monkeypatch):
         assert r.n_states == golden[name]["node"] or golden[name]["fail"] > 0
 
 
+def test_engine_streaming_export_equals_compacting_export(stcsp, golden, monkeypatch):
+    """The edge log leaves the device in chunks WHILE the search runs (engine.hip stream_edges); the result is
+    used as is when no state fails (the shipped examples) and dropped for the compacting export when one does
+    (synthetic instances). Tiny chunks (one per launch round), small pools (the log is reallocated under the
+    stream) and the switched-off path all give the same automaton."""
+    names = ["partialorder_11", "digitinvader3", "juggling_b4_f5_nosym"]
+    synth = stcsp.instances.synthetic(16, 8, 88, 4, 4)
+    def run(m, **kw):
+        e = stcsp.Engine(m, **kw)
+        r = e.solve()
+        a, _ = finish(e, r)
+        a2, _ = finish(e, e.export())  # a second export of the same solve
+        assert a.canonical_sha256() == a2.canonical_sha256()
+        return a.canonical_sha256(), r.counters.dominance, r.counters.fails
+    monkeypatch.setenv("STCSP_STREAM_EXPORT", "0")
+    want = {n: run(stcsp.Model.from_name(n)) for n in names}
+    want_synth = run(stcsp.Model(text=synth))
+    assert want_synth[2] > 0
+    for n in names:
+        assert want[n][0] == golden[n]["canonical_sha256"]
+    monkeypatch.delenv("STCSP_STREAM_EXPORT")
+    for chunk, small, batch in [("1", "0", 0), ("64", "1", 64), ("100000000", "0", 0)]:
+        monkeypatch.setenv("STCSP_STREAM_CHUNK", chunk)
+        if small == "1":
+            monkeypatch.setenv("STCSP_SMALL_POOLS", "1")
+        kw = {"batch_nodes": batch} if batch else {}
+        for n in names:
+            assert run(stcsp.Model.from_name(n), **kw) == want[n], (n, chunk)
+        assert run(stcsp.Model(text=synth), **kw) == want_synth, chunk
+        monkeypatch.delenv("STCSP_SMALL_POOLS", raising=False)
+
+
 MANY_SETS = [
     # `first x` inside arithmetic: one constraint set per captured value (33 = 1 + |D(x)|)
     ("var x:[0,31]; var y:[0,31]; var z:[0,1]; y + z == first x; next z == 1 - z;", 33),
