@@ -366,6 +366,14 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
         p->rounds = rounds + 1;
     }
     if (rl) p->edge_seen[lane] = (unsigned)edges_r;
+    if (lane == 0) p->states_seen = ns_l;
+    if (c.progress) {
+        Progress::Gen *g = &c.progress->gen[(rounds + 1) & 1];
+        if (rl) __hip_atomic_store(&g->edge_seen[lane], (unsigned)edges_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(&g->states_seen, (unsigned)ns_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the generation lands before its number
+        if (lane == 0) __hip_atomic_store(&c.progress->rounds, (unsigned long long)(rounds + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (total > 0) {
         if (sp >= kMaxSegments) {
             if (lane == 0) {
@@ -1058,6 +1066,19 @@ struct StreamView {
     uint32_t from[R];
     uint32_t pref[R + 1];  // prefix sums of the per-region record counts of this chunk
 };
+// ... and the keys of the states [from, to) split into the result's constraint-set id and signature arrays
+// (`cid`, `sig`: pinned host memory the device writes straight into; a state's key never changes once committed)
+__global__ __launch_bounds__(256) void k_stream_keys(const uint32_t *keys, int KL, int sl, uint32_t from, uint32_t to, int32_t *cid, int32_t *sig) {
+    const unsigned long long w = (unsigned long long)from * KL + blockIdx.x * 256ull + threadIdx.x;
+    if (w >= (unsigned long long)to * KL) return;
+    const uint32_t i = (uint32_t)(w / (unsigned)KL);
+    const int j = (int)(w - (unsigned long long)i * KL);
+    const uint32_t v = keys[w];
+    if (j == 0)
+        cid[i] = v == kRootTag ? 0 : (int32_t)v;
+    else if (j - 1 < sl)
+        sig[(size_t)i * sl + (j - 1)] = (int32_t)v;
+}
 __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned long long base, long long *osrc, long long *odst, int32_t *oval) {
     __shared__ unsigned long long tab[4][64];
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

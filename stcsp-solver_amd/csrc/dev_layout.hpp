@@ -64,12 +64,25 @@ struct Plan {
     int chain_small, chain_big, chain_thresh;  // policy: chain_small while a round has <= chain_thresh nodes
     int chain_heavy;                           // a slot stops chaining after this many cycles in one launch
     long long rounds, open_total;
+    unsigned states_seen;   // ... and the number of states in the table then
     unsigned edge_seen[R];  // edge-log cursors at the end of the last accounted round (the host streams the log out while the search runs)
     DevSegment stack[kMaxSegments];
 };
 enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
 enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
        ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
+
+// Progress mirror in pinned HOST memory (streaming export): finalize_round of launch g writes the edge-log cursors and
+// the state count as of the end of launch g into gen[g & 1] and then publishes `rounds` = g, so the host can ship
+// finished parts of the log WHILE a burst of launches is still running. (A generation is shipped one launch late:
+// only when launch g + 1 is seen to have finalized has launch g ended and written its caches back.)
+struct Progress {
+    struct Gen {
+        unsigned edge_seen[R];
+        unsigned states_seen, pad;
+    } gen[2];
+    unsigned long long rounds;
+};
 
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
@@ -106,6 +119,7 @@ struct Ctx {
     const int *code;
     const int *arr_data;
     unsigned long long *stats;
+    Progress *progress;  // null: no mirror
 };
 static_assert(offsetof(Ctx, budget_bitmap) <= 64 * 4, "the node loops' part of Ctx must fit one lane-striped register");
 

@@ -102,7 +102,7 @@ struct stcsp_engine {
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
     // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). STCSP_CHAIN_SMALL / _BIG /
     // _THRESH / _HEAVY override.
-    int chain_small = 4, chain_big = 2, chain_thresh = 4096, chain_heavy = 400000;
+    int chain_small = 4, chain_big = 2, chain_thresh = 16384, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
     DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss;
@@ -156,7 +156,6 @@ struct stcsp_engine {
     DevBuf<uint32_t> d_outdeg, d_post;  // d_post: [0] changed flag, [1] live-edge counter
     long long *h_osrc = nullptr, *h_odst = nullptr;
     int32_t *h_oval = nullptr;
-    uint32_t *h_keys = nullptr;
     uint8_t *h_fail = nullptr;
     size_t h_edge_cap = 0, h_state_cap = 0;
     // device post-processing (dev_postproc.hpp) over the compacted export
@@ -177,9 +176,12 @@ struct stcsp_engine {
         if (h_osrc) (void)hipHostFree(h_osrc);
         if (h_odst) (void)hipHostFree(h_odst);
         if (h_oval) (void)hipHostFree(h_oval);
-        if (h_keys) (void)hipHostFree(h_keys);
         if (h_fail) (void)hipHostFree(h_fail);
         if (h_miss) (void)hipHostFree(h_miss);
+        if (h_progress) (void)hipHostFree(h_progress);
+        if (ev_plan) (void)hipEventDestroy(ev_plan);
+        if (h_cid) (void)hipHostFree(h_cid);
+        if (h_sig) (void)hipHostFree(h_sig);
         if (xstream) (void)hipStreamDestroy(xstream);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -395,6 +397,9 @@ struct stcsp_engine {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&stream));
         HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
+        HIPCHK(hipHostMalloc((void **)&h_progress, sizeof(Progress)));
+        memset(h_progress, 0, sizeof(Progress));
+        HIPCHK(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
         L = CtlLayout(opt.world);
         ctx.N = N;
         ctx.K = K;
@@ -491,6 +496,7 @@ struct stcsp_engine {
     int alloc_states(uint32_t cap) {
         DevBuf<uint32_t> nb;
         HIPCHK(nb.alloc((size_t)cap * ctx.KL));
+        if (xstream) HIPCHK(hipStreamSynchronize(xstream));  // (k_stream_keys may still read the old pool)
         if (d_state_keys.p && n_states)
             HIPCHK(hipMemcpyAsync(nb.p, d_state_keys.p, (size_t)n_states * ctx.KL * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -580,8 +586,46 @@ struct stcsp_engine {
     }
     int read_plan() {
         HIPCHK(hipMemcpyAsync(h_plan, d_plan.p, kPlanHeader, hipMemcpyDeviceToHost, stream));
+        if (streaming && ctx.progress) {
+            // instead of sleeping in the synchronisation: watch the progress mirror and ship what the launches
+            // of the running burst have finished
+            HIPCHK(hipEventRecord(ev_plan, stream));
+            for (;;) {
+                const hipError_t q = hipEventQuery(ev_plan);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) HIPCHK(q);
+                int rc = ship_progress();
+                if (rc != STCSP_OK) return rc;
+            }
+            prog_have = false;  // (the caller ships everything up to the end of the burst)
+        }
         HIPCHK(hipStreamSynchronize(stream));
         levels = h_plan->rounds;
+        return STCSP_OK;
+    }
+    Progress *h_progress = nullptr;
+    hipEvent_t ev_plan = nullptr;
+    Progress::Gen prog_snap{};
+    bool prog_have = false;
+    unsigned long long prog_gen = 0;
+    int ship_progress() {
+        const unsigned long long g = __atomic_load_n(&h_progress->rounds, __ATOMIC_ACQUIRE);
+        if (g == prog_gen) return STCSP_OK;
+        // a later launch has finalized: the launch of the snapshot in hand has ended, its records are in memory
+        if (prog_have) {
+            int rc = stream_edges(prog_snap.edge_seen, false);
+            if (rc == STCSP_OK) rc = stream_states(prog_snap.states_seen);
+            if (rc != STCSP_OK) return rc;
+        }
+        Progress::Gen s;
+        const volatile unsigned *src = (const volatile unsigned *)&h_progress->gen[g & 1];
+        unsigned *dst = (unsigned *)&s;
+        for (size_t i = 0; i < sizeof(Progress::Gen) / sizeof(unsigned); i++) dst[i] = src[i];
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        // (generation g + 1 goes to the other half, g + 2 only starts after g + 1 was published)
+        prog_have = __atomic_load_n(&h_progress->rounds, __ATOMIC_ACQUIRE) == g;
+        prog_snap = s;
+        prog_gen = g;
         return STCSP_OK;
     }
     int replan() {
@@ -598,10 +642,15 @@ struct stcsp_engine {
         levels = 0;
         if (xstream) HIPCHK(hipStreamSynchronize(xstream));
         streamed = 0;
+        streamed_states = 0;
         for (int r = 0; r < R; r++) streamed_r[r] = 0;
         streaming = !sharded && !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
+        memset(h_progress, 0, sizeof(Progress));
+        prog_have = false;
+        prog_gen = 0;
+        ctx.progress = (streaming && !(getenv("STCSP_STREAM_POLL") && atoi(getenv("STCSP_STREAM_POLL")) == 0)) ? h_progress : nullptr;
         translation_stops = 0;
         finished = false;
         exp_on_device = false;
@@ -815,10 +864,12 @@ struct stcsp_engine {
         if (!streaming) return STCSP_OK;
         StreamView v{};
         size_t M = 0;
+        uint32_t to[R];
         for (int r = 0; r < R; r++) {
+            to[r] = std::max(upto[r], streamed_r[r]);  // (an older snapshot than the last one shipped: nothing to do)
             v.from[r] = streamed_r[r];
             v.pref[r] = (uint32_t)M;
-            M += upto[r] - streamed_r[r];
+            M += to[r] - streamed_r[r];
         }
         v.pref[R] = (uint32_t)M;
         if (M == 0 || (!final && M < stream_chunk_min)) return STCSP_OK;
@@ -838,8 +889,39 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
         HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
         HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xstream));
-        for (int r = 0; r < R; r++) streamed_r[r] = upto[r];
+        for (int r = 0; r < R; r++) streamed_r[r] = to[r];
         streamed += M;
+        return STCSP_OK;
+    }
+
+    // ... and the state keys (split into the result's cid / sig arrays by the device, written straight into pinned memory)
+    int32_t *h_cid = nullptr, *h_sig = nullptr;
+    size_t h_key_cap = 0;
+    uint32_t streamed_states = 0;
+    int stream_states(uint32_t upto) {
+        if (upto <= streamed_states) return STCSP_OK;
+        const int sl = std::max(ctx.sig_len, 0);
+        if (h_key_cap < upto) {
+            const size_t cap = std::max<size_t>((size_t)upto + upto / 4 + 256, h_key_cap * 2);
+            int32_t *nc = nullptr, *nsg = nullptr;
+            HIPCHK(hipHostMalloc((void **)&nc, cap * sizeof(int32_t)));
+            HIPCHK(hipHostMalloc((void **)&nsg, std::max<size_t>(cap * sl, 1) * sizeof(int32_t)));
+            HIPCHK(hipStreamSynchronize(xstream));
+            if (streamed_states) {
+                memcpy(nc, h_cid, (size_t)streamed_states * sizeof(int32_t));
+                memcpy(nsg, h_sig, (size_t)streamed_states * sl * sizeof(int32_t));
+            }
+            if (h_cid) (void)hipHostFree(h_cid);
+            if (h_sig) (void)hipHostFree(h_sig);
+            h_cid = nc;
+            h_sig = nsg;
+            h_key_cap = cap;
+        }
+        const unsigned long long words = (unsigned long long)(upto - streamed_states) * ctx.KL;
+        hipLaunchKernelGGL(k_stream_keys, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, xstream, (const uint32_t *)d_state_keys.p, ctx.KL,
+                           ctx.sig_len, streamed_states, upto, h_cid, h_sig);
+        HIPCHK(hipGetLastError());
+        streamed_states = upto;
         return STCSP_OK;
     }
 
@@ -869,30 +951,38 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         const bool prof = opt.flags & STCSP_F_PROFILE;
         const long long rounds_at_entry = levels;
+        uint32_t seen[R], seen_states = 0;
+        bool have_seen = false;  // edge cursors of the last completed burst, not yet handed to stream_edges
         for (;;) {
             if ((rc = flush_ctx())) return rc;
-            for (int k = 0; k < burst; k++) {
-                if (prof) {
-                    if (ev_used == ev_pool.size()) {
-                        hipEvent_t e0, e1;
-                        HIPCHK(hipEventCreate(&e0));
-                        HIPCHK(hipEventCreate(&e1));
-                        ev_pool.emplace_back(e0, e1);
-                    }
-                    HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+            // STCSP_F_PROFILE: one pair of events per BURST (the launches of a burst are back to back on the stream;
+            // a pair per launch costs two more packets between consecutive kernels and ~6 % of a partialorder_14 solve)
+            if (prof) {
+                if (ev_used == ev_pool.size()) {
+                    hipEvent_t e0, e1;
+                    HIPCHK(hipEventCreate(&e0));
+                    HIPCHK(hipEventCreate(&e1));
+                    ev_pool.emplace_back(e0, e1);
                 }
+                HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
+            }
+            for (int k = 0; k < burst; k++) {
                 switch (DR) {
                     case 1: launch_expand<1>(); break;
                     case 2: launch_expand<2>(); break;
                     default: launch_expand<4>(); break;
                 }
                 HIPCHK(hipGetLastError());
-                if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
                 expand_launches++;
             }
+            if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
+            // the device is busy with the burst just enqueued: now is the time to ship the edges of the previous ones
+            if (have_seen && ((rc = stream_edges(seen, false)) || (streaming && (rc = stream_states(seen_states))))) return rc;
             rc = read_plan();
             if (rc != STCSP_OK) return rc;
-            if ((rc = stream_edges(h_plan->edge_seen, false))) return rc;
+            for (int r = 0; r < R; r++) seen[r] = h_plan->edge_seen[r];
+            seen_states = h_plan->states_seen;
+            have_seen = true;
             if (dbg_rounds && burst == 1) {
                 std::vector<unsigned long long> st(kStatSlots * kStatWords);
                 HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1325,7 +1415,7 @@ struct stcsp_engine {
 
     // unsharded export: ok-fixpoint + compaction on the device, result arrays land in pinned memory
     int export_device(stcsp_result *res, stcsp_counters &ctr, size_t &E_out) {
-        const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N;
+        const int N = ctx.N;
         size_t E = 0;
         EdgeView v{};
         v.edges = d_edges.p;
@@ -1353,11 +1443,13 @@ struct stcsp_engine {
         }
         if (!d_post.p) HIPCHK(d_post.alloc(4));
         if (h_state_cap < n_states) {
-            if (h_keys) (void)hipHostFree(h_keys);
             if (h_fail) (void)hipHostFree(h_fail);
             h_state_cap = (size_t)n_states + n_states / 4 + 256;
-            HIPCHK(hipHostMalloc((void **)&h_keys, h_state_cap * KL * sizeof(uint32_t)));
             HIPCHK(hipHostMalloc((void **)&h_fail, h_state_cap));
+        }
+        {  // the keys of the states the search did not get to ship (all of them when streaming is off)
+            int rcs = stream_states(n_states);
+            if (rcs != STCSP_OK) return rcs;
         }
         const bool dbg = getenv("STCSP_DEBUG") != nullptr;
         auto tA = std::chrono::steady_clock::now();
@@ -1368,7 +1460,6 @@ struct stcsp_engine {
             fprintf(stderr, "[export] %-22s %.3f ms\n", what, std::chrono::duration<double>(tB - tA).count() * 1e3);
             tA = tB;
         };
-        HIPCHK(hipMemcpyAsync(h_keys, d_state_keys.p, (size_t)n_states * KL * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
         HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
@@ -1412,17 +1503,13 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         lap("D2H result arrays");
-        r_cid.assign(n_states, 0);
-        r_sig.assign((size_t)n_states * std::max(sl, 0), 0);
+        HIPCHK(hipStreamSynchronize(xstream));  // cid / sig arrays complete
         int64_t ok_states = 0;
-        for (uint32_t i = 0; i < n_states; i++) {
-            uint32_t tag = h_keys[(size_t)i * KL];
-            r_cid[i] = (tag == kRootTag) ? 0 : (int32_t)tag;
-            for (int j = 0; j < sl; j++) r_sig[(size_t)i * sl + j] = (int32_t)h_keys[(size_t)i * KL + 1 + j];
-            if (i) ok_states += !h_fail[i];
-        }
+        for (uint32_t i = 1; i < n_states; i++) ok_states += !h_fail[i];
         ctr.dominance = (int64_t)live - ok_states;  // every ok non-root state is entered by exactly one creating leaf
-        lap("host key split");
+        lap("state arrays");
+        res->state_cid = h_cid;
+        res->state_sig = h_sig;
         res->state_fail = h_fail;
         res->edge_src = (const int64_t *)h_osrc;
         res->edge_dst = (const int64_t *)h_odst;
@@ -1436,10 +1523,22 @@ struct stcsp_engine {
     // Solver::seenConstraints = the initial set + every set a leaf translated to = the distinct set ids of the
     // table's states (the registry may hold more: sets translated ahead of need)
     int32_t used_sets() const {
-        std::vector<int32_t> u(r_cid.begin(), r_cid.end());
-        u.push_back(0);
-        std::sort(u.begin(), u.end());
-        return (int32_t)(std::unique(u.begin(), u.end()) - u.begin());
+        const int32_t *cid = exp_on_device ? h_cid : r_cid.data();
+        std::vector<uint8_t> seen(mgr.sets.size() + 1, 0);
+        std::vector<int32_t> other;  // (sharded runs: ids are content hashes)
+        seen[0] = 1;
+        int32_t n = 1;
+        for (uint32_t i = 0; i < n_states; i++) {
+            const int32_t c = cid[i];
+            if (c >= 0 && (size_t)c < seen.size()) {
+                n += !seen[c];
+                seen[c] = 1;
+            } else {
+                other.push_back(c);
+            }
+        }
+        std::sort(other.begin(), other.end());
+        return n + (int32_t)(std::unique(other.begin(), other.end()) - other.begin());
     }
     int export_result(stcsp_result *res) {
         auto t0 = std::chrono::steady_clock::now();
@@ -1459,8 +1558,6 @@ struct stcsp_engine {
             res->n_sig_vars = mgr.n_sig;
             res->n_until = mgr.n_until;
             res->n_until_cons = mgr.n_until_cons;
-            res->state_cid = r_cid.data();
-            res->state_sig = r_sig.data();
             res->n_edges = (int64_t)E;
             res->n_vars = N;
             res->n_constraint_sets = used_sets();
