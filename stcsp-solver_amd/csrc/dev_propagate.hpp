@@ -111,6 +111,8 @@ struct WaveStats {  // STCSP_PHASES build only: cycle shares of one node
     unsigned rv_blocks = 0, rv_open = 0, rv_lanes = 0;  // blocks, open variables, tuple lanes of the general revisions
     unsigned long long cyc_rv_digits = 0, cyc_rv_eval_bitmap = 0, cyc_rv_eval_code = 0, cyc_rv_support = 0;
     unsigned rv_blocks_code = 0;
+    unsigned batches = 0, batch_items = 0, batch_refused = 0, batch_tuples = 0;
+    unsigned long long cyc_batch = 0, cyc_batch_ab = 0, cyc_batch_de = 0;
 };
 
 // What a wavefront keeps across the nodes it expands in one launch:
@@ -130,6 +132,7 @@ struct WaveEnv {
     int next_abs = -1;  // its eager-arc partner entries (-1: the set has none)
     unsigned long long pm[DR] = {};  // block words (bit l = word q*64 + l) that have an eager partner
     uint32_t smallmask = 0;          // per lane: bits of the lane-revised items in dirty word `lane`
+    uint32_t bmmask = 0;             // per lane: bits of the wavefront-revised items with a tuple bitmap (general kernels only)
     uint32_t e0[DR] = {};            // per lane: partner entry 0 of block word q*64 + lane
     unsigned n_nodes = 0, n_fails = 0, n_leaves = 0, n_requeue = 0, n_revs = 0, n_wave_revs = 0, n_sweeps = 0, n_skipped = 0, n_new = 0;
     unsigned long long n_evals = 0;
@@ -778,12 +781,288 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, 
     return true;
 }
 
+// ---- several dirty wavefront-revised items at once (tuple-parallel batch) ------------------------------------
+// A general revision of a tuple-bitmap constraint rarely needs the wavefront: digitinvader's `A3 == (I ne D0 and ...)`
+// or `next D2 == if ...` have two or three open variables left and 10-30 tuples to look at, and ~20 of them are dirty
+// per node -- one after the other they are ~850 instructions each for a dozen busy lanes. Here up to kBatchItems
+// dirty items are revised TOGETHER against the same snapshot of the block (Jacobi among them, like the sweeps of the
+// small items): lane k < 16 scans the scope of item k (open variables, product of their domain sizes, bitmap index
+// of the singletons), the products are laid side by side on the 64 lanes (a prefix of the items whose products fit),
+// every tuple lane decodes its own tuple of its own item and looks its window of variable 0's bits up (see
+// revise_point), supports are collected with LDS atomics, and the item lanes AND them into the LDS copy of the block.
+// Items with more than 64 tuples / kMaxLowVars open variables, or without a bitmap, are left to revise_point.
+// Returns -1 on a wipe-out, 0 when the FIRST dirty item is not batchable (the caller revises it alone), else the
+// number of items dealt with. `scr`: kBatchItems records of kBatchRec words; `clr`: 64 words.
+constexpr int kBatchItems = 16, kBatchRec = 24;
+static_assert(kBatchItems * kBatchRec <= kMaxLowVars * 64, "the batch records live in the lane-value scratch of the general revision");
+// record of one batch item (16-byte aligned parts, so that a tuple lane fetches it with four wide LDS reads)
+enum { BR_NOPEN = 0, BR_BASE = 1, BR_D0 = 2, BR_BITMAP = 3, BR_WPACK = 4 /* 2 words: block word of open variable q in byte q */, BR_SUP0 = 6,
+       BR_STRIDE = 8, BR_SUP = 16 };
+static_assert(kMaxLowVars <= 6, "batch record layout");
+// per lane: the bits of dirty word `lane` that belong to wavefront-revised items WITH a tuple bitmap (the only ones
+// revise_batch can take); worked out once per constraint set
+template <int DR, bool L>
+__device__ __forceinline__ void load_bmmask(const Ctx &c, const Img<L> &P, int lane, WaveEnv<DR> &E) {
+    uint32_t m = 0;
+    if (lane < E.iw) {
+        for (int b0 = 0; b0 < 32; b0 += 4) {
+            int bm[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int item = lane * 32 + b0 + i;
+                const bool in = item >= E.nsmall && item < E.nitems;
+                bm[i] = in ? P.v(E.items_abs + item * (int)(sizeof(ItemDesc) / 4) + (int)(offsetof(ItemDesc, idx) / 4) + 1) : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) m |= (bm[i] >= 0 ? 1u : 0u) << (b0 + i);
+        }
+    }
+    STCSP_REJOIN();
+    E.bmmask = m;
+}
+template <int DR, bool L>
+__device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<DR> &dom, int lane, uint32_t &dirtyw, int *scr, int *clr,
+                            int *ldom, WaveStats &ws, bool &pm_changed, int &first_item) {
+    // The item records, scopes and strides sit in one run of image sections (engine.hip upload_program): staged in
+    // LDS as a whole or not at all. A partly staged image decides that ONCE here and reads through one pointer
+    // (flat loads, issued together) instead of a staged-or-not branch around every single read.
+    const uint32_t *ip = (L || c.o.code <= G.nlds) ? G.lds : G.p;
+    // ---- A: lane k takes the k-th dirty item that has a tuple bitmap
+    const unsigned long long t_b0 = PHASE_NOW();
+    (void)t_b0;
+    const uint32_t dwv = lane < S.iw ? (dirtyw & S.bmmask) : 0u;
+    int item = 0, ncand = 0;
+    for (unsigned long long m = __ballot(dwv != 0); m && ncand < kBatchItems; m &= m - 1) {
+        const int w = __ffsll((long long)m) - 1;
+        const uint32_t word = rdlane(dwv, w);
+        const int cnt = __popc(word), k = lane - ncand;
+        if (k >= 0 && k < cnt) item = w * 32 + select_kth_fast(word, k);
+        ncand += cnt;
+    }
+    ncand = min(ncand, kBatchItems);
+    first_item = (int)rdlane((uint32_t)item, 0);
+    const bool cand = lane < ncand;
+    // ---- B: item lanes scan their scope, four variables per trip (their reads are issued together)
+    int point = 0, ar = 0, scope_off = 0, bm_off = -1, stride_off = 0, nforb = -1;
+    if (cand) {
+        const int ib = S.items_abs + item * (int)(sizeof(ItemDesc) / 4);
+        point = (int)ip[ib + (int)(offsetof(ItemDesc, point) / 4)];
+        ar = (int)ip[ib + (int)(offsetof(ItemDesc, arity) / 4)];
+        scope_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4)];
+        bm_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 1];
+        stride_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 2];
+        nforb = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 3];
+    }
+    const int rec = (lane & (kBatchItems - 1)) * kBatchRec;
+    int nopen = 0, base = 0, w0 = 0, n0 = 1, largest = 1;
+    unsigned prod = 1;              // tuples to look at: product of the open domains without variable 0 (stops growing past 64)
+    unsigned long long pall = 1;    // product of ALL open domains (for the few-forbidden-tuples test; stops growing past 2^40)
+    uint32_t D0 = 0, wp0 = 0, wp1 = 0;
+    bool wiped = false;
+    const int wbase = point * c.N;
+    for (int j0 = 0; __ballot(cand && j0 < ar); j0 += 4) {
+        int var[4], st[4];
+        uint32_t Dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = cand && j0 + i < ar;
+            var[i] = in ? (int)ip[c.o.scope + scope_off + j0 + i] : 0;
+            st[i] = in ? (int)ip[c.o.strides + stride_off + j0 + i] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) Dv[i] = (uint32_t)ldom[wbase + var[i]];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (cand && j0 + i < ar) {
+                const int w = wbase + var[i];
+                const uint32_t D = Dv[i];
+                const int n = __popc(D);
+                wiped = wiped || n == 0;
+                largest = max(largest, n);
+                if (n > 1 && pall < (1ull << 40)) pall *= (unsigned long long)n;
+                if (j0 + i == 0) {
+                    D0 = D;
+                    w0 = w;
+                    n0 = n;
+                } else if (n > 1) {
+                    if (nopen < 4)
+                        wp0 |= (uint32_t)w << (8 * nopen);
+                    else if (nopen < kMaxLowVars)
+                        wp1 |= (uint32_t)w << (8 * (nopen - 4));
+                    if (nopen < kMaxLowVars) scr[rec + BR_STRIDE + nopen] = st[i];
+                    nopen++;
+                    if (prod <= 64u) prod *= (unsigned)n;
+                } else {
+                    base += (__ffs((int)D) - 1) * st[i];
+                }
+            }
+        }
+    }
+    STCSP_REJOIN();
+    if (__ballot(wiped)) return -1;
+    // constraints with few violating tuples in all: the revision cannot prune unless the product of the other
+    // domains fits into the forbidden set (see revise_point)
+    bool noop = false;
+    if (cand && nforb >= 0) {
+        const int nopen_all = nopen + (n0 > 1 ? 1 : 0);
+        noop = (nforb <= 1 && nopen_all >= 2) || nforb == 0 || nopen_all >= 12 || (1u << nopen_all) > (unsigned)nforb * 32u;
+        if (!noop && nopen_all >= 2) noop = pall > (unsigned long long)nforb * (unsigned long long)largest;
+    }
+    const bool elig = cand && !noop && nopen <= kMaxLowVars && prod <= 64u;
+#ifdef STCSP_PHASES
+    const unsigned long long t_b1 = PHASE_NOW();
+    ws.cyc_batch_ab += t_b1 - t_b0;
+#endif
+    if (!((__ballot(elig || noop)) & 1ull)) {  // the first of them needs revise_point (the caller revises first_item)
+#ifdef STCSP_PHASES
+        ws.batch_refused++;
+#endif
+        return 0;
+    }
+    // ---- C: lay the products side by side (a prefix of the eligible items)
+    const int cnt = elig ? (int)prod : 0;
+    const int incl = wave_scan_add(cnt), excl = incl - cnt;
+    const bool inb = elig && incl <= 64;
+    const unsigned long long inbm = __ballot(inb);
+    const int nb = __popcll(inbm);
+    const int T = inbm ? (int)rdlane((uint32_t)incl, 63 - __clzll((long long)inbm)) : 0;
+    if (inb) {
+        *(uint4 *)&scr[rec + BR_NOPEN] = make_uint4((uint32_t)nopen, (uint32_t)base, D0, (uint32_t)bm_off);
+        *(uint4 *)&scr[rec + BR_WPACK] = make_uint4(wp0, wp1, 0u, 0u);  // (BR_SUP0 = 0)
+        *(uint4 *)&scr[rec + BR_SUP] = make_uint4(0u, 0u, 0u, 0u);
+        *(uint2 *)&scr[rec + BR_SUP + 4] = make_uint2(0u, 0u);
+    }
+    clr[lane] = 0;
+    STCSP_REJOIN();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- D: tuple lanes find their item (the last item lane whose first tuple is <= this lane) and decode their tuple
+    const bool tl = lane < T;
+    int k = 0;
+#pragma unroll
+    for (int step = kBatchItems / 2; step >= 1; step >>= 1) {
+        const int ck = k + step;
+        const int e = __shfl(excl, ck & 63, 64);  // (every lane: cross-lane reads need the source lanes active)
+        if (ck < kBatchItems && e <= lane) k = ck;
+    }
+    int u = lane - __shfl(excl, k, 64);
+    const int rk = k * kBatchRec;
+    const uint4 hd = *(const uint4 *)&scr[rk + BR_NOPEN];
+    const uint2 wp = *(const uint2 *)&scr[rk + BR_WPACK];
+    const uint4 s03 = *(const uint4 *)&scr[rk + BR_STRIDE];
+    const uint2 s45 = *(const uint2 *)&scr[rk + BR_STRIDE + 4];
+    const int nop = tl ? (int)hd.x : 0;
+    const int wq[6] = {(int)(wp.x & 255u), (int)((wp.x >> 8) & 255u), (int)((wp.x >> 16) & 255u), (int)(wp.x >> 24), (int)(wp.y & 255u), (int)((wp.y >> 8) & 255u)};
+    const int sq[6] = {(int)s03.x, (int)s03.y, (int)s03.z, (int)s03.w, (int)s45.x, (int)s45.y};
+    uint32_t Dq[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) Dq[q] = q < nop ? (uint32_t)ldom[wq[q]] : 1u;
+    int idx = (int)hd.y;
+    uint32_t pack = 0;  // value bit of open variable q in bits [5q, 5q + 5)
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        if (__ballot(q < nop)) {
+            const uint32_t D = Dq[q];
+            const int n = __popc(D);
+            const int qd = small_div(u, n);
+            const int bit = select_kth_fast(D, u - qd * n);
+            if (q < nop) {
+                u = qd;
+                idx += bit * sq[q];
+                pack |= (uint32_t)bit << (5 * q);
+            }
+        }
+    }
+    // ---- E: the window of variable 0's bits at this tuple; a satisfied tuple supports all of its values
+    if (tl) {
+        const uint32_t D0k = hd.z;
+        const int tw = c.o.tables + (int)hd.w + (idx >> 5), sh = idx & 31;
+        const uint32_t wlo = (uint32_t)G.vc(tw);
+        const uint32_t whi = (sh + (31 - __clz((int)D0k)) >= 32) ? (uint32_t)G.vc(tw + 1) : 0u;
+        const uint32_t sup0 = (uint32_t)((((unsigned long long)whi << 32) | wlo) >> sh) & D0k;
+        if (sup0) {
+            atomicOr((unsigned *)&scr[rk + BR_SUP0], sup0);
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q < nop) atomicOr((unsigned *)&scr[rk + BR_SUP + q], 1u << ((pack >> (5 * q)) & 31u));
+        }
+    }
+    STCSP_REJOIN();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#ifdef STCSP_PHASES
+    const unsigned long long t_b2 = PHASE_NOW();
+    ws.cyc_batch_de += t_b2 - t_b1;
+#endif
+    // ---- F: item lanes intersect the block with the supports
+    const int wo[6] = {(int)(wp0 & 255u), (int)((wp0 >> 8) & 255u), (int)((wp0 >> 16) & 255u), (int)(wp0 >> 24), (int)(wp1 & 255u), (int)((wp1 >> 8) & 255u)};
+    bool nosup = false;
+    uint32_t s0 = 0, sup[6] = {0, 0, 0, 0, 0, 0};
+    if (inb) {
+        const uint4 a = *(const uint4 *)&scr[rec + BR_SUP];
+        const uint2 b = *(const uint2 *)&scr[rec + BR_SUP + 4];
+        s0 = (uint32_t)scr[rec + BR_SUP0];
+        sup[0] = a.x, sup[1] = a.y, sup[2] = a.z, sup[3] = a.w, sup[4] = b.x, sup[5] = b.y;
+        nosup = s0 == 0;  // no satisfying tuple at all
+        if (s0 != D0) atomicAnd((unsigned *)&ldom[w0], s0);
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < nopen) atomicAnd((unsigned *)&ldom[wo[q]], sup[q]);
+    }
+    STCSP_REJOIN();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    S.n_revs += (unsigned)nb;
+    S.n_wave_revs += (unsigned)nb;
+    S.n_evals += (unsigned)T;
+#ifdef STCSP_PHASES
+    ws.batches++;
+    ws.batch_items += (unsigned)nb;
+    ws.batch_tuples += (unsigned)T;
+#endif
+    if (__ballot(nosup)) return -1;
+    // ---- G: read the intersection back; changed words re-dirty the items that read them
+    bool empty = false;
+#pragma unroll
+    for (int q = 0; q < DR; q++) {
+        const int ix = q * 64 + lane;
+        const uint32_t nd = ix < c.NK ? (uint32_t)ldom[ix] : dom.r[q];
+        if (__ballot(ix < c.NK && nd == 0)) empty = true;
+        const unsigned long long cm = __ballot(nd != dom.r[q]);
+        dom.r[q] = nd;
+        mark_dirty_rows<L>(G, S.rows_abs, S.iw, q, cm, lane, dirtyw);
+        pm_changed = pm_changed || (cm & S.pm[q]) != 0;
+    }
+    if (empty) return -1;
+    // an item whose open variables ended up with exactly the supports IT computed is at its fixpoint (its satisfying
+    // tuples consist of supported values only); one that lost more through another item of the batch stays dirty
+    bool selfok = cand && noop;
+    if (inb) {
+        bool ok = (uint32_t)ldom[w0] == s0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) ok = ok && (q >= nopen || (uint32_t)ldom[wo[q]] == sup[q]);
+        selfok = ok;
+    }
+    if (selfok) atomicOr((unsigned *)&clr[item >> 5], 1u << (item & 31));
+    STCSP_REJOIN();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dirtyw &= ~(uint32_t)clr[lane];
+#ifdef STCSP_PHASES
+    ws.cyc_batch += PHASE_NOW() - t_b0;
+#endif
+    return nb + __popcll(__ballot(cand && noop));
+}
+
 template <int DR, bool L, bool CS, bool LITE>
 __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, int *ldom, Dom<DR> &dom,
                             const NodeHdr &hd, int gw, WaveEnv<DR> &S, BranchOut &bo, LeafOut<DR> &lo) {
     const int set = hd.set;
     const uint32_t seed = hd.seed, expire = hd.expire;
-    if (set != S.set) load_env<DR, L>(c, P, set, lane, S);
+    if (set != S.set) {
+        load_env<DR, L>(c, P, set, lane, S);
+        if constexpr (!LITE) load_bmmask<DR, L>(c, P, lane, S);
+    }
 
     // ---- propagate to the GAC fixpoint (role of generalisedArcConsistent, :617-706). Work items
     // are (constraint, time point) pairs; the dirty mask is lane-striped (lane w holds word w).
@@ -1008,9 +1287,32 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         const unsigned long long t_wv = PHASE_NOW();
         unsigned long long dm = __ballot(dirtyw != 0);
         if (!dm) break;
+        int forced = -1;  // the item revise_batch wants revised alone
+        if constexpr (!LITE) {
+            if (__ballot(lane < S.iw && (dirtyw & S.bmmask) != 0)) {
+                bool pm_changed = false;
+                int first = 0;
+                const int br = revise_batch<DR, L>(c, P, S, dom, lane, dirtyw, lds_vals, lds_stk, ldom, ws, pm_changed, first);
+                if (br != 0) {
+                    consistent = br > 0;
+                    need_close = pm_changed && S.next_abs >= 0;
+                    ws.cyc_wave += PHASE_NOW() - t_wv;
+                    if (++guard > (1u << 20)) {
+                        S.err = max(S.err, (unsigned)ERR_WATCHDOG);
+                        consistent = false;
+                    }
+                    continue;
+                }
+                forced = first;
+            }
+        }
         int wl = __ffsll((long long)dm) - 1;
         uint32_t word = rdlane(dirtyw, wl);
         int b = __ffs((int)word) - 1;
+        if (forced >= 0) {
+            wl = forced >> 5;
+            b = forced & 31;
+        }
         int item = wl * 32 + b;
         if (lane == wl) dirtyw &= ~(1u << b);
         // the item record holds the point and the constraint's descriptor: one per-lane read, broadcast by readlane
@@ -1054,6 +1356,13 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_CYC_RV_EVAL_CODE, ws.cyc_rv_eval_code);
         add_stats(c, gw, ST_CYC_RV_SUPPORT, ws.cyc_rv_support);
         add_stats(c, gw, ST_RV_BLOCKS_CODE, ws.rv_blocks_code);
+        add_stats(c, gw, ST_BATCHES, ws.batches);
+        add_stats(c, gw, ST_BATCH_ITEMS, ws.batch_items);
+        add_stats(c, gw, ST_BATCH_REFUSED, ws.batch_refused);
+        add_stats(c, gw, ST_BATCH_TUPLES, ws.batch_tuples);
+        add_stats(c, gw, ST_CYC_BATCH, ws.cyc_batch);
+        add_stats(c, gw, ST_CYC_BATCH_AB, ws.cyc_batch_ab);
+        add_stats(c, gw, ST_CYC_BATCH_DE, ws.cyc_batch_de);
     }
 #endif
     if (!consistent) {

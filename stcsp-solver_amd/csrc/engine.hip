@@ -1100,6 +1100,15 @@ struct stcsp_engine {
                     (unsigned long long)(tot[ST_RV_BLOCKS] - tot[ST_RV_BLOCKS_CODE]),
                     (double)tot[ST_CYC_RV_EVAL_CODE] / std::max<double>(1.0, (double)tot[ST_RV_BLOCKS_CODE]), (unsigned long long)tot[ST_RV_BLOCKS_CODE],
                     (double)tot[ST_CYC_RV_SUPPORT] / tot[ST_RV_BLOCKS]);
+        if (tot[ST_BATCHES] + tot[ST_BATCH_REFUSED])
+            fprintf(stderr, "[phases] batched revisions: %.2f batches per node, %.2f items and %.1f tuple lanes each, %.0f cycles each (scan %.0f, tuples %.0f); %.2f refused scans per node (%.0f cycles each)\n",
+                    (double)tot[ST_BATCHES] / tot[ST_NODES], (double)tot[ST_BATCH_ITEMS] / std::max<double>(1.0, (double)tot[ST_BATCHES]),
+                    (double)tot[ST_BATCH_TUPLES] / std::max<double>(1.0, (double)tot[ST_BATCHES]),
+                    (double)tot[ST_CYC_BATCH] / std::max<double>(1.0, (double)tot[ST_BATCHES]),
+                    (double)tot[ST_CYC_BATCH_AB] / std::max<double>(1.0, (double)(tot[ST_BATCHES] + tot[ST_BATCH_REFUSED])),
+                    (double)tot[ST_CYC_BATCH_DE] / std::max<double>(1.0, (double)tot[ST_BATCHES]),
+                    (double)tot[ST_BATCH_REFUSED] / tot[ST_NODES],
+                    (double)tot[ST_CYC_BATCH_AB] / std::max<double>(1.0, (double)(tot[ST_BATCHES] + tot[ST_BATCH_REFUSED])));
         if (tot[ST_NODES])
             fprintf(stderr, "[phases] cycles/node: closures of the next arcs %.0f, leaf part of process_node (transition, signature, hash, time shift) %.0f\n",
                     (double)tot[ST_CYC_CLOSE] / tot[ST_NODES], (double)tot[ST_CYC_LEAF] / tot[ST_NODES]);
@@ -1545,8 +1554,8 @@ struct stcsp_engine {
         HIPCHK(hipSetDevice(device));
         const int KL = ctx.KL, sl = ctx.sig_len, N = ctx.N, ES = ctx.ES;
         if (!sharded && !(opt.flags & STCSP_F_KEEP_RAW_EDGES) && !getenv("STCSP_HOST_EXPORT")) {
-            stcsp_counters ctr{};
-            int rcc = read_counters(ctr);
+            stcsp_counters ctr = snap;  // (finish() read them)
+            int rcc = finished ? STCSP_OK : read_counters(ctr);
             if (rcc != STCSP_OK) return rcc;
             memset(res, 0, sizeof *res);
             size_t E = 0;
