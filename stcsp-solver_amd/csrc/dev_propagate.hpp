@@ -793,32 +793,64 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, 
 // Items with more than 64 tuples / kMaxLowVars open variables, or without a bitmap, are left to revise_point.
 // Returns -1 on a wipe-out, 0 when the FIRST dirty item is not batchable (the caller revises it alone), else the
 // number of items dealt with. `scr`: kBatchItems records of kBatchRec words; `clr`: 64 words.
-constexpr int kBatchItems = 16, kBatchRec = 24;
+constexpr int kBatchItems = 16, kBatchRec = 24, kBatchArity = 16;
 static_assert(kBatchItems * kBatchRec <= kMaxLowVars * 64, "the batch records live in the lane-value scratch of the general revision");
 // record of one batch item (16-byte aligned parts, so that a tuple lane fetches it with four wide LDS reads)
 enum { BR_NOPEN = 0, BR_BASE = 1, BR_D0 = 2, BR_BITMAP = 3, BR_WPACK = 4 /* 2 words: block word of open variable q in byte q */, BR_SUP0 = 6,
-       BR_STRIDE = 8, BR_SUP = 16 };
+       BR_META = 7 /* w0 | tuples << 8 | eligible << 16 | no-op << 17 */, BR_STRIDE = 8, BR_SUP = 16 };
 static_assert(kMaxLowVars <= 6, "batch record layout");
-// per lane: the bits of dirty word `lane` that belong to wavefront-revised items WITH a tuple bitmap (the only ones
-// revise_batch can take); worked out once per constraint set
+// per lane: the bits of dirty word `lane` that belong to wavefront-revised items WITH a tuple bitmap and a scope of
+// at most kBatchArity variables (the only ones revise_batch can take); worked out once per constraint set
 template <int DR, bool L>
 __device__ __forceinline__ void load_bmmask(const Ctx &c, const Img<L> &P, int lane, WaveEnv<DR> &E) {
     uint32_t m = 0;
     if (lane < E.iw) {
         for (int b0 = 0; b0 < 32; b0 += 4) {
-            int bm[4];
+            int bm[4], ar[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int item = lane * 32 + b0 + i;
                 const bool in = item >= E.nsmall && item < E.nitems;
-                bm[i] = in ? P.v(E.items_abs + item * (int)(sizeof(ItemDesc) / 4) + (int)(offsetof(ItemDesc, idx) / 4) + 1) : -1;
+                const int ib = E.items_abs + item * (int)(sizeof(ItemDesc) / 4);
+                bm[i] = in ? P.v(ib + (int)(offsetof(ItemDesc, idx) / 4) + 1) : -1;
+                ar[i] = in ? P.v(ib + (int)(offsetof(ItemDesc, arity) / 4)) : 0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) m |= (bm[i] >= 0 ? 1u : 0u) << (b0 + i);
+            for (int i = 0; i < 4; i++) m |= ((bm[i] >= 0 && ar[i] <= kBatchArity) ? 1u : 0u) << (b0 + i);
         }
     }
     STCSP_REJOIN();
     E.bmmask = m;
+}
+// reductions over the rows of 16 lanes (every lane ends up with its row's result): DPP rotations, no LDS
+__device__ __forceinline__ int row_ror(int v, int by) {
+    switch (by) {
+        case 8: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    }
+}
+__device__ __forceinline__ int row_sum(int v) {
+    v += row_ror(v, 8);
+    v += row_ror(v, 4);
+    v += row_ror(v, 2);
+    v += row_ror(v, 1);
+    return v;
+}
+__device__ __forceinline__ int row_max(int v) {
+    v = max(v, row_ror(v, 8));
+    v = max(v, row_ror(v, 4));
+    v = max(v, row_ror(v, 2));
+    v = max(v, row_ror(v, 1));
+    return v;
+}
+__device__ __forceinline__ int row_prod_capped(int v) {  // factors <= 32; the product stops growing at 2^15
+    v = min(v * row_ror(v, 8), 1 << 15);
+    v = min(v * row_ror(v, 4), 1 << 15);
+    v = min(v * row_ror(v, 2), 1 << 15);
+    v = min(v * row_ror(v, 1), 1 << 15);
+    return v;
 }
 template <int DR, bool L>
 __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<DR> &dom, int lane, uint32_t &dirtyw, int *scr, int *clr,
@@ -827,7 +859,7 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     // LDS as a whole or not at all. A partly staged image decides that ONCE here and reads through one pointer
     // (flat loads, issued together) instead of a staged-or-not branch around every single read.
     const uint32_t *ip = (L || c.o.code <= G.nlds) ? G.lds : G.p;
-    // ---- A: lane k takes the k-th dirty item that has a tuple bitmap
+    // ---- A: slot k (lane k for now) takes the k-th dirty item that has a tuple bitmap
     const unsigned long long t_b0 = PHASE_NOW();
     (void)t_b0;
     const uint32_t dwv = lane < S.iw ? (dirtyw & S.bmmask) : 0u;
@@ -841,101 +873,96 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     }
     ncand = min(ncand, kBatchItems);
     first_item = (int)rdlane((uint32_t)item, 0);
-    const bool cand = lane < ncand;
-    // ---- B: item lanes scan their scope, four variables per trip (their reads are issued together)
-    int point = 0, ar = 0, scope_off = 0, bm_off = -1, stride_off = 0, nforb = -1;
-    if (cand) {
-        const int ib = S.items_abs + item * (int)(sizeof(ItemDesc) / 4);
-        point = (int)ip[ib + (int)(offsetof(ItemDesc, point) / 4)];
-        ar = (int)ip[ib + (int)(offsetof(ItemDesc, arity) / 4)];
-        scope_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4)];
-        bm_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 1];
-        stride_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 2];
-        nforb = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 3];
+    // ---- B: the scopes are scanned FOUR ITEMS AT A TIME, one row of 16 lanes per item and one lane per scope
+    // variable: open variables (domain not a singleton; variable 0 is never enumerated, see revise_point), the
+    // number of tuples = product of their domain sizes, the bitmap index of the singletons -- row reductions. The
+    // row leader (scope position 0 = variable 0) writes the item's record, the open variables their block word and
+    // stride at their rank. Scanning stops once the tuples found fill the 64 lanes.
+    const int j = lane & 15, row = lane >> 4;
+    int scanned = 0, tuples_found = 0;
+    for (int p0 = 0; p0 < ncand && tuples_found < 64; p0 += 4) {
+        const int slot = p0 + row;
+        const bool vs = slot < ncand;
+        const int it_ = __shfl(item, slot & 63, 64);
+        const int it = vs ? it_ : first_item;
+        const int ib = S.items_abs + it * (int)(sizeof(ItemDesc) / 4);
+        const int point = (int)ip[ib + (int)(offsetof(ItemDesc, point) / 4)];
+        const int ar = (int)ip[ib + (int)(offsetof(ItemDesc, arity) / 4)];
+        const int scope_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4)];
+        const int bm_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 1];
+        const int stride_off = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 2];
+        const int nforb = (int)ip[ib + (int)(offsetof(ItemDesc, idx) / 4) + 3];
+        const bool in = vs && j < ar;
+        const int jj = in ? j : 0;
+        const int var = (int)ip[c.o.scope + scope_off + jj];
+        const int st = (int)ip[c.o.strides + stride_off + jj];
+        const int w = point * c.N + var;
+        const uint32_t D = (uint32_t)ldom[w];
+        const int n = in ? __popc(D) : 1;
+        if (__ballot(in && n == 0)) return -1;
+        const bool open = in && n > 1 && j != 0;
+        const unsigned rowbits = (unsigned)(__ballot(open) >> (16 * row)) & 0xffffu;
+        const int nopen = __popc(rowbits), rank = __popc(rowbits & ((1u << j) - 1u));
+        const int prod = row_prod_capped(open ? n : 1);
+        const int base = row_sum((in && n == 1 && j != 0) ? (__ffs((int)D) - 1) * st : 0);
+        // constraints with few violating tuples in all: the revision cannot prune unless the product of the other
+        // domains fits into the forbidden set (see revise_point)
+        bool noop = false;
+        if (__ballot(vs && nforb >= 0)) {
+            const int largest = row_max(n);
+            const int n0 = __shfl(n, lane & 48, 64);
+            const int nopen_all = nopen + (n0 > 1 ? 1 : 0);
+            const long long pall = (long long)prod * (long long)n0;  // (prod capped at 2^15: still far above nforb * largest <= 2048)
+            noop = nforb >= 0 && ((nforb <= 1 && nopen_all >= 2) || nforb == 0 || nopen_all >= 12 || (1u << min(nopen_all, 31)) > (unsigned)nforb * 32u ||
+                                  (nopen_all >= 2 && pall > (long long)nforb * (long long)largest));
+        }
+        const bool elig = !noop && nopen <= kMaxLowVars && prod <= 64;
+        const int rec = (slot & (kBatchItems - 1)) * kBatchRec;
+        if (vs && j == 0) {  // the leader holds variable 0: D, w are its domain and block word
+            *(uint4 *)&scr[rec + BR_NOPEN] = make_uint4((uint32_t)nopen, (uint32_t)base, D, (uint32_t)bm_off);
+            scr[rec + BR_SUP0] = 0;
+            scr[rec + BR_META] = w | ((elig ? prod : 0) << 8) | ((elig ? 1 : 0) << 16) | ((noop ? 1 : 0) << 17);
+            *(uint4 *)&scr[rec + BR_SUP] = make_uint4(0u, 0u, 0u, 0u);
+            *(uint2 *)&scr[rec + BR_SUP + 4] = make_uint2(0u, 0u);
+        }
+        if (open && rank < kMaxLowVars) {
+            ((unsigned char *)&scr[rec + BR_WPACK])[rank] = (unsigned char)w;
+            scr[rec + BR_STRIDE + rank] = st;
+        }
+        STCSP_REJOIN();
+        const unsigned long long lead = __ballot(vs && j == 0 && elig);
+        for (unsigned long long m = lead; m; m &= m - 1) tuples_found += (int)rdlane((uint32_t)prod, __ffsll((long long)m) - 1);
+        scanned = min(p0 + 4, ncand);
+        if (p0 == 0 && !(__ballot(elig || noop) & 1ull)) {  // the first of them needs revise_point (the caller revises first_item)
+#ifdef STCSP_PHASES
+            ws.cyc_batch_ab += PHASE_NOW() - t_b0;
+            ws.batch_refused++;
+#endif
+            return 0;
+        }
     }
+    clr[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- C: item lanes (lane k = slot k) read their records back and lay the products side by side (a prefix of the eligible items)
+    const bool cand = lane < scanned;
     const int rec = (lane & (kBatchItems - 1)) * kBatchRec;
-    int nopen = 0, base = 0, w0 = 0, n0 = 1, largest = 1;
-    unsigned prod = 1;              // tuples to look at: product of the open domains without variable 0 (stops growing past 64)
-    unsigned long long pall = 1;    // product of ALL open domains (for the few-forbidden-tuples test; stops growing past 2^40)
-    uint32_t D0 = 0, wp0 = 0, wp1 = 0;
-    bool wiped = false;
-    const int wbase = point * c.N;
-    for (int j0 = 0; __ballot(cand && j0 < ar); j0 += 4) {
-        int var[4], st[4];
-        uint32_t Dv[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool in = cand && j0 + i < ar;
-            var[i] = in ? (int)ip[c.o.scope + scope_off + j0 + i] : 0;
-            st[i] = in ? (int)ip[c.o.strides + stride_off + j0 + i] : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) Dv[i] = (uint32_t)ldom[wbase + var[i]];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (cand && j0 + i < ar) {
-                const int w = wbase + var[i];
-                const uint32_t D = Dv[i];
-                const int n = __popc(D);
-                wiped = wiped || n == 0;
-                largest = max(largest, n);
-                if (n > 1 && pall < (1ull << 40)) pall *= (unsigned long long)n;
-                if (j0 + i == 0) {
-                    D0 = D;
-                    w0 = w;
-                    n0 = n;
-                } else if (n > 1) {
-                    if (nopen < 4)
-                        wp0 |= (uint32_t)w << (8 * nopen);
-                    else if (nopen < kMaxLowVars)
-                        wp1 |= (uint32_t)w << (8 * (nopen - 4));
-                    if (nopen < kMaxLowVars) scr[rec + BR_STRIDE + nopen] = st[i];
-                    nopen++;
-                    if (prod <= 64u) prod *= (unsigned)n;
-                } else {
-                    base += (__ffs((int)D) - 1) * st[i];
-                }
-            }
-        }
-    }
-    STCSP_REJOIN();
-    if (__ballot(wiped)) return -1;
-    // constraints with few violating tuples in all: the revision cannot prune unless the product of the other
-    // domains fits into the forbidden set (see revise_point)
-    bool noop = false;
-    if (cand && nforb >= 0) {
-        const int nopen_all = nopen + (n0 > 1 ? 1 : 0);
-        noop = (nforb <= 1 && nopen_all >= 2) || nforb == 0 || nopen_all >= 12 || (1u << nopen_all) > (unsigned)nforb * 32u;
-        if (!noop && nopen_all >= 2) noop = pall > (unsigned long long)nforb * (unsigned long long)largest;
-    }
-    const bool elig = cand && !noop && nopen <= kMaxLowVars && prod <= 64u;
+    const uint4 my = *(const uint4 *)&scr[rec + BR_NOPEN];
+    const uint2 mywp = *(const uint2 *)&scr[rec + BR_WPACK];
+    const int meta = scr[rec + BR_META];
+    const int nopen = (int)my.x, w0 = meta & 255;
+    const uint32_t D0 = my.z, wp0 = mywp.x, wp1 = mywp.y;
+    const bool elig = cand && ((meta >> 16) & 1), noop = cand && ((meta >> 17) & 1);
 #ifdef STCSP_PHASES
     const unsigned long long t_b1 = PHASE_NOW();
     ws.cyc_batch_ab += t_b1 - t_b0;
 #endif
-    if (!((__ballot(elig || noop)) & 1ull)) {  // the first of them needs revise_point (the caller revises first_item)
-#ifdef STCSP_PHASES
-        ws.batch_refused++;
-#endif
-        return 0;
-    }
-    // ---- C: lay the products side by side (a prefix of the eligible items)
-    const int cnt = elig ? (int)prod : 0;
+    const int cnt = elig ? ((meta >> 8) & 255) : 0;
     const int incl = wave_scan_add(cnt), excl = incl - cnt;
     const bool inb = elig && incl <= 64;
     const unsigned long long inbm = __ballot(inb);
     const int nb = __popcll(inbm);
     const int T = inbm ? (int)rdlane((uint32_t)incl, 63 - __clzll((long long)inbm)) : 0;
-    if (inb) {
-        *(uint4 *)&scr[rec + BR_NOPEN] = make_uint4((uint32_t)nopen, (uint32_t)base, D0, (uint32_t)bm_off);
-        *(uint4 *)&scr[rec + BR_WPACK] = make_uint4(wp0, wp1, 0u, 0u);  // (BR_SUP0 = 0)
-        *(uint4 *)&scr[rec + BR_SUP] = make_uint4(0u, 0u, 0u, 0u);
-        *(uint2 *)&scr[rec + BR_SUP + 4] = make_uint2(0u, 0u);
-    }
-    clr[lane] = 0;
-    STCSP_REJOIN();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     // ---- D: tuple lanes find their item (the last item lane whose first tuple is <= this lane) and decode their tuple
     const bool tl = lane < T;
     int k = 0;
@@ -1036,7 +1063,7 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     if (empty) return -1;
     // an item whose open variables ended up with exactly the supports IT computed is at its fixpoint (its satisfying
     // tuples consist of supported values only); one that lost more through another item of the batch stays dirty
-    bool selfok = cand && noop;
+    bool selfok = noop;
     if (inb) {
         bool ok = (uint32_t)ldom[w0] == s0;
 #pragma unroll
@@ -1051,7 +1078,7 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
 #ifdef STCSP_PHASES
     ws.cyc_batch += PHASE_NOW() - t_b0;
 #endif
-    return nb + __popcll(__ballot(cand && noop));
+    return nb + __popcll(__ballot(noop));
 }
 
 template <int DR, bool L, bool CS, bool LITE>
