@@ -317,8 +317,8 @@ __device__ __forceinline__ int select_kth_fast(uint32_t m, int k) {
     if (k >= (int)(m & 1u)) pos += 1;
     return pos;
 }
-// x / d for 0 <= x < 64, 1 <= d <= 64 via one reciprocal (exact: (x + 0.5) / d is never within
-// 1/128 of an integer, far above float error)
+// x / d for 0 <= x < 4096, 1 <= d <= 64 via one reciprocal (exact: (x + 0.5) / d is never within
+// 1/128 of an integer, far above the float error of 4096 * 2^-22)
 __device__ __forceinline__ int small_div(int x, int d) {
     return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
 }
@@ -793,11 +793,11 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, 
 // Items with more than 64 tuples / kMaxLowVars open variables, or without a bitmap, are left to revise_point.
 // Returns -1 on a wipe-out, 0 when the FIRST dirty item is not batchable (the caller revises it alone), else the
 // number of items dealt with. `scr`: kBatchItems records of kBatchRec words; `clr`: 64 words.
-constexpr int kBatchItems = 16, kBatchRec = 24, kBatchArity = 16;
+constexpr int kBatchItems = 16, kBatchRec = 24, kBatchArity = 16, kBatchTuples = 256;  // tuples of one batch: looked at 64 at a time
 static_assert(kBatchItems * kBatchRec <= kMaxLowVars * 64, "the batch records live in the lane-value scratch of the general revision");
 // record of one batch item (16-byte aligned parts, so that a tuple lane fetches it with four wide LDS reads)
 enum { BR_NOPEN = 0, BR_BASE = 1, BR_D0 = 2, BR_BITMAP = 3, BR_WPACK = 4 /* 2 words: block word of open variable q in byte q */, BR_SUP0 = 6,
-       BR_META = 7 /* w0 | tuples << 8 | eligible << 16 | no-op << 17 */, BR_STRIDE = 8, BR_SUP = 16 };
+       BR_META = 7 /* w0 | tuples << 8 | eligible << 20 | no-op << 21 */, BR_STRIDE = 8, BR_SUP = 16 };
 static_assert(kMaxLowVars <= 6, "batch record layout");
 // per lane: the bits of dirty word `lane` that belong to wavefront-revised items WITH a tuple bitmap and a scope of
 // at most kBatchArity variables (the only ones revise_batch can take); worked out once per constraint set
@@ -880,7 +880,7 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     // stride at their rank. Scanning stops once the tuples found fill the 64 lanes.
     const int j = lane & 15, row = lane >> 4;
     int scanned = 0, tuples_found = 0;
-    for (int p0 = 0; p0 < ncand && tuples_found < 64; p0 += 4) {
+    for (int p0 = 0; p0 < ncand && tuples_found < kBatchTuples; p0 += 4) {
         const int slot = p0 + row;
         const bool vs = slot < ncand;
         const int it_ = __shfl(item, slot & 63, 64);
@@ -916,12 +916,12 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
             noop = nforb >= 0 && ((nforb <= 1 && nopen_all >= 2) || nforb == 0 || nopen_all >= 12 || (1u << min(nopen_all, 31)) > (unsigned)nforb * 32u ||
                                   (nopen_all >= 2 && pall > (long long)nforb * (long long)largest));
         }
-        const bool elig = !noop && nopen <= kMaxLowVars && prod <= 64;
+        const bool elig = !noop && nopen <= kMaxLowVars && prod <= kBatchTuples;
         const int rec = (slot & (kBatchItems - 1)) * kBatchRec;
         if (vs && j == 0) {  // the leader holds variable 0: D, w are its domain and block word
             *(uint4 *)&scr[rec + BR_NOPEN] = make_uint4((uint32_t)nopen, (uint32_t)base, D, (uint32_t)bm_off);
             scr[rec + BR_SUP0] = 0;
-            scr[rec + BR_META] = w | ((elig ? prod : 0) << 8) | ((elig ? 1 : 0) << 16) | ((noop ? 1 : 0) << 17);
+            scr[rec + BR_META] = w | ((elig ? prod : 0) << 8) | ((elig ? 1 : 0) << 20) | ((noop ? 1 : 0) << 21);
             *(uint4 *)&scr[rec + BR_SUP] = make_uint4(0u, 0u, 0u, 0u);
             *(uint2 *)&scr[rec + BR_SUP + 4] = make_uint2(0u, 0u);
         }
@@ -952,67 +952,71 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     const int meta = scr[rec + BR_META];
     const int nopen = (int)my.x, w0 = meta & 255;
     const uint32_t D0 = my.z, wp0 = mywp.x, wp1 = mywp.y;
-    const bool elig = cand && ((meta >> 16) & 1), noop = cand && ((meta >> 17) & 1);
+    const bool elig = cand && ((meta >> 20) & 1), noop = cand && ((meta >> 21) & 1);
 #ifdef STCSP_PHASES
     const unsigned long long t_b1 = PHASE_NOW();
     ws.cyc_batch_ab += t_b1 - t_b0;
 #endif
-    const int cnt = elig ? ((meta >> 8) & 255) : 0;
+    const int cnt = elig ? ((meta >> 8) & 4095) : 0;
     const int incl = wave_scan_add(cnt), excl = incl - cnt;
-    const bool inb = elig && incl <= 64;
+    const bool inb = elig && incl <= kBatchTuples;
     const unsigned long long inbm = __ballot(inb);
     const int nb = __popcll(inbm);
     const int T = inbm ? (int)rdlane((uint32_t)incl, 63 - __clzll((long long)inbm)) : 0;
-    // ---- D: tuple lanes find their item (the last item lane whose first tuple is <= this lane) and decode their tuple
-    const bool tl = lane < T;
-    int k = 0;
+    // ---- D: tuple lanes, 64 tuples per trip, find their item (the last item lane whose first tuple is <= theirs) and decode their tuple
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool tl = t < T;
+        int k = 0;
 #pragma unroll
-    for (int step = kBatchItems / 2; step >= 1; step >>= 1) {
-        const int ck = k + step;
-        const int e = __shfl(excl, ck & 63, 64);  // (every lane: cross-lane reads need the source lanes active)
-        if (ck < kBatchItems && e <= lane) k = ck;
-    }
-    int u = lane - __shfl(excl, k, 64);
-    const int rk = k * kBatchRec;
-    const uint4 hd = *(const uint4 *)&scr[rk + BR_NOPEN];
-    const uint2 wp = *(const uint2 *)&scr[rk + BR_WPACK];
-    const uint4 s03 = *(const uint4 *)&scr[rk + BR_STRIDE];
-    const uint2 s45 = *(const uint2 *)&scr[rk + BR_STRIDE + 4];
-    const int nop = tl ? (int)hd.x : 0;
-    const int wq[6] = {(int)(wp.x & 255u), (int)((wp.x >> 8) & 255u), (int)((wp.x >> 16) & 255u), (int)(wp.x >> 24), (int)(wp.y & 255u), (int)((wp.y >> 8) & 255u)};
-    const int sq[6] = {(int)s03.x, (int)s03.y, (int)s03.z, (int)s03.w, (int)s45.x, (int)s45.y};
-    uint32_t Dq[6];
+        for (int step = kBatchItems / 2; step >= 1; step >>= 1) {
+            const int ck = k + step;
+            const int e = __shfl(excl, ck & 63, 64);  // (every lane: cross-lane reads need the source lanes active)
+            if (ck < kBatchItems && e <= t) k = ck;
+        }
+        int u = t - __shfl(excl, k, 64);
+        const int rk = k * kBatchRec;
+        const uint4 hd = *(const uint4 *)&scr[rk + BR_NOPEN];
+        const uint2 wp = *(const uint2 *)&scr[rk + BR_WPACK];
+        const uint4 s03 = *(const uint4 *)&scr[rk + BR_STRIDE];
+        const uint2 s45 = *(const uint2 *)&scr[rk + BR_STRIDE + 4];
+        const int nop = tl ? (int)hd.x : 0;
+        const int wq[6] = {(int)(wp.x & 255u), (int)((wp.x >> 8) & 255u), (int)((wp.x >> 16) & 255u), (int)(wp.x >> 24), (int)(wp.y & 255u), (int)((wp.y >> 8) & 255u)};
+        const int sq[6] = {(int)s03.x, (int)s03.y, (int)s03.z, (int)s03.w, (int)s45.x, (int)s45.y};
+        uint32_t Dq[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) Dq[q] = q < nop ? (uint32_t)ldom[wq[q]] : 1u;
-    int idx = (int)hd.y;
-    uint32_t pack = 0;  // value bit of open variable q in bits [5q, 5q + 5)
+        for (int q = 0; q < 6; q++) Dq[q] = q < nop ? (uint32_t)ldom[wq[q]] : 1u;
+        int idx = (int)hd.y;
+        uint32_t pack = 0;  // value bit of open variable q in bits [5q, 5q + 5)
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        if (__ballot(q < nop)) {
-            const uint32_t D = Dq[q];
-            const int n = __popc(D);
-            const int qd = small_div(u, n);
-            const int bit = select_kth_fast(D, u - qd * n);
-            if (q < nop) {
-                u = qd;
-                idx += bit * sq[q];
-                pack |= (uint32_t)bit << (5 * q);
+        for (int q = 0; q < 6; q++) {
+            if (__ballot(q < nop)) {
+                const uint32_t D = Dq[q];
+                const int n = __popc(D);
+                const int qd = small_div(u, n);  // (u < kBatchTuples: the reciprocal is still exact)
+                const int bit = select_kth_fast(D, u - qd * n);
+                if (q < nop) {
+                    u = qd;
+                    idx += bit * sq[q];
+                    pack |= (uint32_t)bit << (5 * q);
+                }
             }
         }
-    }
-    // ---- E: the window of variable 0's bits at this tuple; a satisfied tuple supports all of its values
-    if (tl) {
-        const uint32_t D0k = hd.z;
-        const int tw = c.o.tables + (int)hd.w + (idx >> 5), sh = idx & 31;
-        const uint32_t wlo = (uint32_t)G.vc(tw);
-        const uint32_t whi = (sh + (31 - __clz((int)D0k)) >= 32) ? (uint32_t)G.vc(tw + 1) : 0u;
-        const uint32_t sup0 = (uint32_t)((((unsigned long long)whi << 32) | wlo) >> sh) & D0k;
-        if (sup0) {
-            atomicOr((unsigned *)&scr[rk + BR_SUP0], sup0);
+        // ---- E: the window of variable 0's bits at this tuple; a satisfied tuple supports all of its values
+        if (tl) {
+            const uint32_t D0k = hd.z;
+            const int tw = c.o.tables + (int)hd.w + (idx >> 5), sh = idx & 31;
+            const uint32_t wlo = (uint32_t)G.vc(tw);
+            const uint32_t whi = (sh + (31 - __clz((int)D0k)) >= 32) ? (uint32_t)G.vc(tw + 1) : 0u;
+            const uint32_t sup0 = (uint32_t)((((unsigned long long)whi << 32) | wlo) >> sh) & D0k;
+            if (sup0) {
+                atomicOr((unsigned *)&scr[rk + BR_SUP0], sup0);
 #pragma unroll
-            for (int q = 0; q < 6; q++)
-                if (q < nop) atomicOr((unsigned *)&scr[rk + BR_SUP + q], 1u << ((pack >> (5 * q)) & 31u));
+                for (int q = 0; q < 6; q++)
+                    if (q < nop) atomicOr((unsigned *)&scr[rk + BR_SUP + q], 1u << ((pack >> (5 * q)) & 31u));
+            }
         }
+        STCSP_REJOIN();
     }
     STCSP_REJOIN();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
