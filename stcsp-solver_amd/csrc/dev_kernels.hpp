@@ -368,11 +368,9 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
     if (rl) p->edge_seen[lane] = (unsigned)edges_r;
     if (lane == 0) p->states_seen = ns_l;
     if (c.progress) {
-        Progress::Gen *g = &c.progress->gen[(rounds + 1) & 1];
-        if (rl) __hip_atomic_store(&g->edge_seen[lane], (unsigned)edges_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane == 0) __hip_atomic_store(&g->states_seen, (unsigned)ns_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the generation lands before its number
-        if (lane == 0) __hip_atomic_store(&c.progress->rounds, (unsigned long long)(rounds + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long tag = (unsigned long long)(rounds + 1) << 32;
+        if (rl) __hip_atomic_store(&c.progress->edge_seen[lane], tag | (unsigned)edges_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(&c.progress->states_seen, tag | ns_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (total > 0) {
         if (sp >= kMaxSegments) {

@@ -73,15 +73,13 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
        ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
 
 // Progress mirror in pinned HOST memory (streaming export): finalize_round of launch g writes the edge-log cursors and
-// the state count as of the end of launch g into gen[g & 1] and then publishes `rounds` = g, so the host can ship
-// finished parts of the log WHILE a burst of launches is still running. (A generation is shipped one launch late:
-// only when launch g + 1 is seen to have finalized has launch g ended and written its caches back.)
+// the state count as of the end of launch g, each word tagged with g (high half), so the host can ship finished parts
+// of the log WHILE a burst of launches is still running. No fence orders the words (a system-scope release would
+// write the whole L2 back, every round): a snapshot is valid when all its tags agree. (It is shipped one launch
+// late: only when launch g + 1 is seen to have finalized has launch g ended and written its caches back.)
 struct Progress {
-    struct Gen {
-        unsigned edge_seen[R];
-        unsigned states_seen, pad;
-    } gen[2];
-    unsigned long long rounds;
+    unsigned long long edge_seen[R];  // tag << 32 | cursor
+    unsigned long long states_seen;   // tag << 32 | count
 };
 
 struct ImgOff {

@@ -129,7 +129,7 @@ struct stcsp_engine {
     DevBuf<Ctx> d_ctx;       // device copy of ctx for k_expand (re-uploaded before a burst)
     Ctx *h_ctx = nullptr;    // pinned staging copy
     Plan *h_plan = nullptr;  // pinned mirror of the plan header (everything before the stack)
-    int burst = 8;           // rounds enqueued per host synchronisation
+    int burst = 8;           // rounds enqueued per host synchronisation (32 for unsharded solves: a launch past the end costs ~3 us, a synchronisation ~25)
     std::vector<uint32_t> edge_count = std::vector<uint32_t>(R, 0);
     uint32_t n_states = 0;
     bool begun = false, finished = false;
@@ -476,6 +476,7 @@ struct stcsp_engine {
         HIPCHK(d_ctx.alloc(1));
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
+        if (!sharded && !(opt.time_limit_s > 0) && !(opt.max_search_nodes > 0)) burst = 32;  // (budgets are checked between bursts)
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_SMALL")) chain_small = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_BIG")) chain_big = std::max(1, atoi(ev));
@@ -605,26 +606,35 @@ struct stcsp_engine {
     }
     Progress *h_progress = nullptr;
     hipEvent_t ev_plan = nullptr;
-    Progress::Gen prog_snap{};
+    struct ProgressSnap {
+        uint32_t edge_seen[R];
+        uint32_t states_seen;
+    } prog_snap{};
     bool prog_have = false;
     unsigned long long prog_gen = 0;
     int ship_progress() {
-        const unsigned long long g = __atomic_load_n(&h_progress->rounds, __ATOMIC_ACQUIRE);
+        // a snapshot = all words carrying the same tag (= number of the launch that wrote them)
+        const volatile unsigned long long *src = (const volatile unsigned long long *)h_progress;
+        const unsigned long long s0 = src[R];
+        const unsigned long long g = s0 >> 32;
         if (g == prog_gen) return STCSP_OK;
-        // a later launch has finalized: the launch of the snapshot in hand has ended, its records are in memory
+        ProgressSnap s;
+        s.states_seen = (uint32_t)s0;
+        bool whole = true;
+        for (int r = 0; r < R; r++) {
+            const unsigned long long e = src[r];
+            whole = whole && (e >> 32) == g;
+            s.edge_seen[r] = (uint32_t)e;
+        }
+        if (!whole) return STCSP_OK;  // launch g is still writing (or g + 1 already is): look again
+        // launch g has finalized, so the launch of the snapshot in hand has ended: its records are in memory
         if (prog_have) {
             int rc = stream_edges(prog_snap.edge_seen, false);
             if (rc == STCSP_OK) rc = stream_states(prog_snap.states_seen);
             if (rc != STCSP_OK) return rc;
         }
-        Progress::Gen s;
-        const volatile unsigned *src = (const volatile unsigned *)&h_progress->gen[g & 1];
-        unsigned *dst = (unsigned *)&s;
-        for (size_t i = 0; i < sizeof(Progress::Gen) / sizeof(unsigned); i++) dst[i] = src[i];
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        // (generation g + 1 goes to the other half, g + 2 only starts after g + 1 was published)
-        prog_have = __atomic_load_n(&h_progress->rounds, __ATOMIC_ACQUIRE) == g;
         prog_snap = s;
+        prog_have = true;
         prog_gen = g;
         return STCSP_OK;
     }
