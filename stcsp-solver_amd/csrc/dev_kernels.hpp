@@ -28,9 +28,13 @@ __device__ __forceinline__ Ctx ctx_from(const uint32_t (&hot)[2]) {
     return cr;
 }
 
+// the dynamic LDS of the launch, by name: the sibling stack is addressed through it (word offsets) so that its
+// accesses are LDS instructions whatever the compiler can or cannot infer about a pointer into it
+extern __shared__ __attribute__((aligned(16))) int stcsp_lds[];
+
 template <int DR, bool L, bool CS, bool LITE>
 __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk, int *ldom,
-                            WaveEnv<DR> &env) {
+                            int sib_off, WaveEnv<DR> &env) {
     const Ctx c0 = ctx_from(hot);
     const Ctx &c = c0;
     const int r = gw % R, i = gw / R;
@@ -80,9 +84,40 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
 #ifdef STCSP_PHASES
     if (lane == 0) add_stats(c, gw, ST_CYC_LOAD, t_b - t_a);
 #endif
+    // Sibling stack (LDS, kSibDepth node records): the upper child of a bisection waits here instead of going to the
+    // frontier; when the chain's path ends (failure, or a leaf into a known state) before the slot has used its
+    // expansions, the slot goes on with the youngest sibling -- depth-first inside the slot. Whatever is left when the
+    // slot stops goes to the frontier in one piece. Small rounds (fewer nodes than wavefronts, where a round is one
+    // chain of dependent expansions long) get more out of each launch this way: partialorder_14 40 -> 31 rounds.
+    // Only chains of more than two expansions use it: in the big rounds (chain = 2, every slot has plenty of input
+    // nodes) parking a child in LDS for one step is pure overhead.
+    int sd = 0;
+#ifdef STCSP_PHASES
+    // (hipcc 7.2 fails on this one instantiation of the instrumented build -- "Illegal instruction detected:
+    // V_CMP_NE_U32_e32 0, $src_shared_base" -- with the stack in it; the product build is not affected)
+    const bool use_sib = chain > 2 && !(DR == 4 && L && CS && !LITE);
+#else
+    const bool use_sib = chain > 2;
+#endif
+    // the siblings still waiting + `extra` more records go to the frontier: one cursor bump for all of them
+    auto flush_siblings = [&](const Ctx &c, uint32_t extra, uint32_t &pos) -> bool {
+        pos = 0;
+        if (sd == 0 && extra == 0) return true;
+        if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], (uint32_t)sd + extra);
+        pos = rflu(pos);
+        if (pos + (uint32_t)sd + extra > a.out_cap) {
+            env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
+            return false;
+        }
+        uint32_t *dst = out_region + (size_t)(pos + extra) * c.NS;  // [pos, pos + extra): the caller's records
+        for (int w = lane; w < sd * c.NS; w += 64) dst[w] = (uint32_t)stcsp_lds[sib_off + w];
+        STCSP_REJOIN();
+        return true;
+    };
     for (int step = 1;; step++) {
         BranchOut bo;     // outputs of this expansion only (nothing of them is carried round the loop)
         LeafOut<DR> lo;
+        sd = rfl(sd);
         // The header is wave-uniform, but values carried round a loop whose exits the compiler cannot
         // prove uniform are treated as divergent (VGPRs, vector instead of scalar descriptor loads:
         // +30..60 VGPRs and a wavefront of occupancy per SIMD). Pin them to SGPRs every iteration.
@@ -125,25 +160,63 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
             }
         } phase_end{c, gw, lane, t_p, t_c};
 #endif
-        if (oc == OC_FAIL) return;
+        // the path of this chain ended here: go on with the youngest sibling, or hand the rest to the frontier
+#define STCSP_PATH_END()                                                                   \
+    {                                                                                      \
+        if (sd == 0) return;                                                               \
+        if (last) {                                                                        \
+            uint32_t fpos;                                                                 \
+            flush_siblings(c, 0u, fpos);                                                   \
+            return;                                                                        \
+        }                                                                                  \
+        sd--;                                                                              \
+        const int sib = sib_off + sd * c.NS;                                               \
+        hd.h0 = rflu((uint32_t)stcsp_lds[sib]);                                            \
+        hd.h1 = rflu((uint32_t)stcsp_lds[sib + 1]);                                        \
+        const uint32_t sw2 = rflu((uint32_t)stcsp_lds[sib + 2]);                           \
+        hd.set = (int)(sw2 & 0xffffu);                                                     \
+        hd.seed = sw2 >> 16;                                                               \
+        hd.expire = rflu((uint32_t)stcsp_lds[sib + 3]);                                    \
+        _Pragma("unroll") for (int q = 0; q < DR; q++) {                                   \
+            const int idx = q * 64 + lane;                                                 \
+            dom.r[q] = idx < c.NK ? (uint32_t)stcsp_lds[sib + 4 + idx] : 0u;               \
+        }                                                                                  \
+        continue;                                                                          \
+    }
+        if (oc == OC_FAIL) STCSP_PATH_END();
         if (oc == OC_BRANCH) {
-            const uint32_t n_out = last ? 2u : 1u;
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], n_out);
-            pos = rflu(pos);
-            if (pos + n_out > a.out_cap) {
-                env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
-                return;
-            }
             const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
             Dom<DR> child = dom;
-            child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: always to the frontier
-            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
+            child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: waits on the sibling stack, or goes to the frontier
             dom.set(bo.bvar, bo.D & bo.lowmask, lane);     // lower half: next in the chain, or stored too
-            if (last) {
+            if (use_sib && !last && sd < kSibDepth) {
+                const int sb = sib_off + sd * c.NS;
+                if (lane < 4) stcsp_lds[sb + lane] = (int)(lane == 0 ? hd.h0 : (lane == 1 ? hd.h1 : (lane == 2 ? cw2 : hd.expire)));
+#pragma unroll
+                for (int q = 0; q < DR; q++) {
+                    const int idx = q * 64 + lane;
+                    if (idx < c.NK) stcsp_lds[sb + 4 + idx] = (int)child.r[q];
+                }
+                STCSP_REJOIN();
+                sd++;
+                hd.seed = (uint32_t)(bo.bvar + 1);
+                continue;
+            }
+            if (last) {  // both children and the waiting siblings
+                uint32_t pos;
+                if (!flush_siblings(c, 2u, pos)) return;
+                store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
                 store_node<DR>(out_region + (size_t)(pos + 1) * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, dom, lane);
                 return;
             }
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], 1u);
+            pos = rflu(pos);
+            if (pos + 1u > a.out_cap) {
+                env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
+                return;
+            }
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
             hd.seed = (uint32_t)(bo.bvar + 1);
             continue;
         }
@@ -156,7 +229,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
                 return;
             }
             store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
-            return;
+            STCSP_PATH_END();
         }
         // leaf
         // sharded runs: a leaf whose successor state belongs to another shard becomes a candidate
@@ -185,18 +258,23 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
                 if (idx < c.NK) blk[idx] = lo.nblk[q];
             }
             STCSP_REJOIN();
-            return;
+            STCSP_PATH_END();
         }
         // commit right here, the leaf's data never leaves the registers
 #ifdef STCSP_X_NOCOMMIT
-        return;
+        STCSP_PATH_END();
 #endif
         CommitOut co = table_commit<DR>(c, lane, ro, lo.kw, lo.h, hd.h0, hd.h1, lo.next_set, lo.next_tag, lo.evals);
-        if (!co.ok) env.err = max(env.err, co.err);
-        if (!(co.ok && co.is_new)) return;
+        if (!co.ok) {
+            env.err = max(env.err, co.err);
+            return;
+        }
+        if (!co.is_new) STCSP_PATH_END();
         env.n_new++;
         if (last) {
             env.err = max(env.err, emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk));
+            uint32_t fpos;
+            flush_siblings(c, 0u, fpos);
             return;
         }
         // the leaf opened a new state: its first node is next in the chain
@@ -209,6 +287,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
 #pragma unroll
         for (int q = 0; q < DR; q++) dom.r[q] = lo.nblk[q];
     }
+#undef STCSP_PATH_END
 }
 
 __device__ __forceinline__ uint32_t ald(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -514,6 +593,7 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront, then its counters
+    const int sib_off = img_words + wib * per_wave + wave_sib_offset(c.NK, c.stack_slots, LITE);  // word offset in the launch's LDS
     Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
     // the plan is read through the constant address space (scalar loads): a load through a generic pointer is a
     // source of divergence to the compiler, and one divergent loop exit makes every value carried round the
@@ -537,7 +617,7 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     uint32_t hot[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
-    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, env);
+    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
     flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
     __syncthreads();
 #ifdef STCSP_PHASES

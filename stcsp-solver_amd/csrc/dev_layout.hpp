@@ -24,8 +24,13 @@ enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWS
 constexpr int kLdsStatWords = 12;
 // LDS words of one wavefront: [lane-enumerated values | expression stack] (general revisions only) + the
 // AND-accumulator copy of the block + the counters. LITE kernels (no general revision) keep the last part only.
-__host__ __device__ inline int wave_scratch_words(int NK, int stack_slots, bool lite) {
+// ... + the sibling stack of the chained expansions (dev_kernels.hpp expand_node): kSibDepth node records.
+constexpr int kSibDepth = 4;
+__host__ __device__ inline int wave_sib_offset(int NK, int stack_slots, bool lite) {
     return (lite ? 0 : (kMaxLowVars + stack_slots) * 64) + ((NK + kLdsStatWords + 63) & ~63);
+}
+__host__ __device__ inline int wave_scratch_words(int NK, int stack_slots, bool lite) {
+    return wave_sib_offset(NK, stack_slots, lite) + kSibDepth * ((4 + NK + 3) & ~3);
 }
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;

@@ -21,7 +21,11 @@ constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revis
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
-constexpr unsigned long long kBudgetBitmapIters = 4096;  // odometer steps a bitmap revision may take
+// odometer steps (blocks of <= 64 tuples, ~1.1 k cycles each when the bitmap is in HBM) one bitmap revision may take; longer
+// ones are skipped. 4096 made juggling_b4_f5_nosym 15.8 ms (1.5 with 64) and digitinvader9 23.4 (20.8): a revision that
+// long rarely prunes enough to pay for itself. 16 is faster still but propagates less than the reference does
+// (791 instead of 781 nodes on juggling_b4_f5_nosym).
+constexpr unsigned long long kBudgetBitmapIters = 32;
 constexpr unsigned long long kBudgetCodeIters = 32;      // ... and an interpreted one
 constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan

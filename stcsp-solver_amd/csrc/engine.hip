@@ -100,9 +100,11 @@ struct stcsp_engine {
     size_t arena_soft_words = 0;
     // expansions per slot and launch (expand_node): chain_small while a round has <= chain_thresh
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
-    // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). STCSP_CHAIN_SMALL / _BIG /
-    // _THRESH / _HEAVY override.
-    int chain_small = 4, chain_big = 2, chain_thresh = 16384, chain_heavy = 400000;
+    // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 8 under the general kernels
+    // (expensive nodes: fewer, longer rounds -- digitinvader9 27.2 -> 23.4 ms), 4 under the LITE ones
+    // (partialorder_12/14/16 lose 3-10 % with 8). STCSP_CHAIN_SMALL / _BIG / _THRESH / _HEAVY override.
+    bool chain_small_auto = true;
+    int chain_small = 4, chain_big = 2, chain_thresh = 65536, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
     DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss;
@@ -478,7 +480,10 @@ struct stcsp_engine {
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (!sharded && !(opt.time_limit_s > 0) && !(opt.max_search_nodes > 0)) burst = 32;  // (budgets are checked between bursts)
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
-        if (const char *ev = getenv("STCSP_CHAIN_SMALL")) chain_small = std::max(1, atoi(ev));
+        if (const char *ev = getenv("STCSP_CHAIN_SMALL")) {
+            chain_small = std::max(1, atoi(ev));
+            chain_small_auto = false;
+        }
         if (const char *ev = getenv("STCSP_CHAIN_BIG")) chain_big = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_THRESH")) chain_thresh = std::max(0, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_HEAVY")) chain_heavy = std::max(1, atoi(ev));
@@ -674,6 +679,7 @@ struct stcsp_engine {
         memset(h_plan, 0, sizeof(Plan));
         chunk_r = chunk_r0;
         h_plan->chunk_r = chunk_r;
+        if (chain_small_auto) chain_small = lite ? 4 : 8;
         h_plan->chain_small = chain_small;
         h_plan->chain_big = chain_big;
         h_plan->chain_thresh = chain_thresh;

@@ -237,8 +237,7 @@ def test_engine_array_validity_semantics(stcsp, RefOracle):
 def test_engine_batch_shrinks_at_arena_soft_limit(stcsp, golden, monkeypatch):
     """An automatic launch batch (256 k nodes) halves itself instead of growing the frontier arena
     past its soft limit (explosive searches: memory ~ depth x batch); same automaton."""
-    monkeypatch.setenv("STCSP_ARENA_SOFT_MB", "16")
-    rounds = {}
+    monkeypatch.setenv("STCSP_ARENA_SOFT_MB", "4")
     for name in ["partialorder_14", "digitinvader5"]:
         m = stcsp.Model.from_name(name)
         e = stcsp.Engine(m)
@@ -246,7 +245,10 @@ def test_engine_batch_shrinks_at_arena_soft_limit(stcsp, golden, monkeypatch):
         a, _ = finish(e, r)
         assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
         assert r.counters.search_nodes == golden[name]["search"]
-        rounds[name] = r.counters.levels
+    # partialorder_16 (frontier of several hundred thousand nodes): the limited run really uses smaller rounds
+    big = stcsp.Model(text=stcsp.instances.partialorder(16))
+    rl = stcsp.Engine(big).solve()
     monkeypatch.delenv("STCSP_ARENA_SOFT_MB")
-    e = stcsp.Engine(stcsp.Model.from_name("partialorder_14"))
-    assert e.solve().counters.levels < rounds["partialorder_14"]  # the limited run really used smaller rounds
+    ru = stcsp.Engine(big).solve()
+    assert (rl.counters.search_nodes, rl.n_states) == (ru.counters.search_nodes, ru.n_states) == (6112188, 130048)
+    assert ru.counters.levels < rl.counters.levels
