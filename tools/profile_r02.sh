@@ -13,6 +13,10 @@ cd /tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-other-workloads"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_p14 -- $B --steps 5 --warmup 2 > $OUT/stats_p14.json 2> $OUT/stats_p14.err
 echo "stats p14 done"
+# the same with the export's D2H traffic out of the way: under the tracer the copies of the streaming export run as
+# blit kernels on the CUs (HSA_ENABLE_SDMA=0 reproduces it without the tracer), which slows k_expand by ~40 %
+STCSP_STREAM_EXPORT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_p14_nostream -- $B --steps 5 --warmup 2 > $OUT/stats_p14_nostream.json 2> $OUT/stats_p14_nostream.err
+echo "stats p14 (no streaming) done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$name -- $B --steps 1 --warmup 0 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err

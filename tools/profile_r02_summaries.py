@@ -53,6 +53,34 @@ json.dump({"_source": src + ": separate passes `rocprofv3 --pmc FETCH_SIZE --ker
           open(os.path.join(OUT, "r02_p14_traffic.json"), "w"), indent=1)
 sb = bench_line(os.path.join(RAW, "stats_p14.json"))
 json.dump(sb, open(os.path.join(OUT, "r02_p14_bench_under_rocprof.json"), "w"), indent=1)
+
+
+def trace_summary(run, bench):
+    """k_expand dispatch durations of the kernel trace: all of them (what --stats averages: cold solves with their
+    pool growth and the no-op launches past the end of a burst included) and the timed steps only."""
+    import csv
+    rows = list(csv.DictReader(open(newest(os.path.join(RAW, run, "**", "*_kernel_trace.csv")))))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_expand" in r["Kernel_Name"]]
+    n_timed = bench["roofline"]["launches"]
+    timed = d[-n_timed:]
+    copies = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "copyBuffer" in r["Kernel_Name"]]
+    return {"k_expand_dispatches": len(d), "avg_us_all": sum(d) / len(d), "timed_dispatches": len(timed), "avg_us_timed_steps": sum(timed) / len(timed),
+            "kernel_ms_per_timed_solve": sum(timed) / bench["steps"] / 1e3, "bench_avg_launch_us_hip_events": bench["roofline"]["avg_launch_us"],
+            "blit_copy_kernels": len(copies), "blit_copy_avg_us": (sum(copies) / len(copies)) if copies else 0.0,
+            "bench_value": bench["value"], "bench_search_only_nodes_per_s": bench["search_only_nodes_per_s"]}
+
+
+ts = {"_source": src + ": per-dispatch durations from the kernel traces of the two --stats runs. `streaming`: the bench command as is; under the "
+                   "tracer the D2H copies of the streaming export run as blit kernels (__amd_rocclr_copyBuffer) on the CUs instead of on the SDMA "
+                   "engines, k_expand slows from ~107 to ~150 us per launch (HSA_ENABLE_SDMA=0 gives the same figure without the tracer). "
+                   "`no_streaming`: STCSP_STREAM_EXPORT=0, the kernel by itself.",
+      "streaming": trace_summary("stats_p14", sb)}
+if os.path.isdir(os.path.join(RAW, "stats_p14_nostream")):
+    sbn = bench_line(os.path.join(RAW, "stats_p14_nostream.json"))
+    shutil.copy(newest(os.path.join(RAW, "stats_p14_nostream", "**", "*_kernel_stats.csv")), os.path.join(OUT, "r02_p14_nostream_kernel_stats.csv"))
+    ts["no_streaming"] = trace_summary("stats_p14_nostream", sbn)
+json.dump(ts, open(os.path.join(OUT, "r02_p14_kernel_trace_summary.json"), "w"), indent=1)
+print("trace summary", json.dumps({k: ({a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()} if isinstance(v, dict) else "") for k, v in ts.items() if k != "_source"}))
 d = json.load(open(os.path.join(OUT, "r02_p14_pmc.json")))
 print("p14 per node", {k: round(v, 1) for k, v in d["per_node"].items()}, "wave cycles", round(d["wave_cycles_per_node_x4"]),
       {k: round(v, 3) for k, v in d["share_of_wave_cycles"].items()})
