@@ -266,7 +266,8 @@ def main():
         p = model.problem.contents
         cfg = {"workload": f"{args.workload}.csp (generated by stcsp-solver_amd/instances.py; "
                            f"{p.n_vars} vars incl. aux, prefix K={p.prefix_k}, whole frontier resident in HBM)",
-               "timed_region": "solve entry -> raw automaton on the host (search + ok-fixpoint + compaction + D2H)",
+               "timed_region": "solve entry -> raw automaton on the host (search, with the edge log and state keys streamed to pinned host arrays "
+                               "on a second stream while it runs, + ok-fixpoint + the last chunks; compaction + D2H when a state failed)",
                "nodes_per_step": nodes // args.steps, "leaves_per_step": leaves // args.steps,
                "launch_rounds_per_step": int(levels),
                "per_node": {"item_revisions": revs / max(nodes, 1), "tuple_evaluations": evals / max(nodes, 1),
@@ -301,7 +302,10 @@ def main():
             "data": "synthetic",
             "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_expand",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r02_p14_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
+                                           "(tools/profile_r02.sh), gfx950-corrected, divided by this run's launches per solve" if traffic is not None else None,
+                         "kernel": "k_expand",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,
                          "launches": k_launches, "bytes_per_node": b_node, "bytes_per_leaf": b_leaf,
                          "kernel_time_share": k_time / elapsed if elapsed > 0 else None},

@@ -4,7 +4,7 @@ The reference ships 26 example inputs (`examples/*.csp`: partialorder_{10..14},
 juggling_b{4,5,6}_f{4,5,6}[_nosym], digitinvader{1..9}).  They are three parametric model
 families; this module regenerates them from their parameters so that tests and the bench run on
 a GPU box where the reference tree does not exist, and so that larger members of each family
-(e.g. partialorder_16) can be produced.  `tests/test_instances.py` checks, when
+(e.g. partialorder_16) can be produced.  `tests/test_frontend.py::test_generated_instances_equal_reference_examples` checks, when
 /root/reference is present, that every generated text lexes to exactly the same token stream as
 the shipped example of the same name (same statements, same order => same model, same
 constraint queue order).
