@@ -180,11 +180,13 @@ struct stcsp_engine {
         if (h_oval) (void)hipHostFree(h_oval);
         if (h_fail) (void)hipHostFree(h_fail);
         if (h_miss) (void)hipHostFree(h_miss);
+        if (h_stats) (void)hipHostFree(h_stats);
         if (h_progress) (void)hipHostFree(h_progress);
         if (ev_plan) (void)hipEventDestroy(ev_plan);
         if (h_cid) (void)hipHostFree(h_cid);
         if (h_sig) (void)hipHostFree(h_sig);
         if (xstream) (void)hipStreamDestroy(xstream);
+        if (xstream2) (void)hipStreamDestroy(xstream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -399,6 +401,7 @@ struct stcsp_engine {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&stream));
         HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&xstream2, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc((void **)&h_progress, sizeof(Progress)));
         memset(h_progress, 0, sizeof(Progress));
         HIPCHK(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
@@ -502,7 +505,7 @@ struct stcsp_engine {
     int alloc_states(uint32_t cap) {
         DevBuf<uint32_t> nb;
         HIPCHK(nb.alloc((size_t)cap * ctx.KL));
-        if (xstream) HIPCHK(hipStreamSynchronize(xstream));  // (k_stream_keys may still read the old pool)
+        { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }  // (k_stream_keys may still read the old pool)
         if (d_state_keys.p && n_states)
             HIPCHK(hipMemcpyAsync(nb.p, d_state_keys.p, (size_t)n_states * ctx.KL * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -515,7 +518,7 @@ struct stcsp_engine {
     int alloc_edges(uint32_t cap) {
         DevBuf<uint32_t> nb;
         HIPCHK(nb.alloc((size_t)R * cap * ctx.ES));
-        if (xstream) HIPCHK(hipStreamSynchronize(xstream));  // (a streaming chunk may still read the old log)
+        { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }  // (a streaming chunk may still read the old log)
         if (d_edges.p)
             for (int r = 0; r < R; r++)
                 if (edge_count[r])
@@ -655,7 +658,7 @@ struct stcsp_engine {
         n_states = 0;
         truncated = false;
         levels = 0;
-        if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+        { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
         streamed = 0;
         streamed_states = 0;
         for (int r = 0; r < R; r++) streamed_r[r] = 0;
@@ -824,7 +827,13 @@ struct stcsp_engine {
     // ---- streaming export (unsharded solves that will be exported): the edge log is transposed into the result
     // arrays and copied to the host chunk by chunk on a second stream WHILE the search runs (the copy of
     // partialorder_14's 95 MB is 1.7 ms at PCIe speed: more than a third of its whole solve when done afterwards)
-    hipStream_t xstream = nullptr;
+    hipStream_t xstream = nullptr, xstream2 = nullptr;  // chunks alternate between the two: one transposes while the other's copies are on the link
+    unsigned chunk_no = 0;
+    int sync_xstreams() {
+        if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+        if (xstream2) HIPCHK(hipStreamSynchronize(xstream2));
+        return STCSP_OK;
+    }
     bool streaming = false;
     size_t streamed = 0;                 // edge records staged so far
     uint32_t streamed_r[R] = {0};        // ... per region of the edge log
@@ -838,7 +847,7 @@ struct stcsp_engine {
             HIPCHK(ns.alloc(cap));
             HIPCHK(nd.alloc(cap));
             HIPCHK(nv.alloc(cap * N));
-            if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
             if (streamed) {
                 HIPCHK(hipMemcpy(ns.p, d_osrc.p, streamed * sizeof(long long), hipMemcpyDeviceToDevice));
                 HIPCHK(hipMemcpy(nd.p, d_odst.p, streamed * sizeof(long long), hipMemcpyDeviceToDevice));
@@ -858,7 +867,7 @@ struct stcsp_engine {
             HIPCHK(hipHostMalloc((void **)&ns, cap * sizeof(long long)));
             HIPCHK(hipHostMalloc((void **)&nd, cap * sizeof(long long)));
             HIPCHK(hipHostMalloc((void **)&nv, cap * N * sizeof(int32_t)));
-            if (xstream) HIPCHK(hipStreamSynchronize(xstream));
+            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
             if (streamed) {
                 memcpy(ns, h_osrc, streamed * sizeof(long long));
                 memcpy(nd, h_odst, streamed * sizeof(long long));
@@ -900,11 +909,12 @@ struct stcsp_engine {
         v.ES = ctx.ES;
         v.N = ctx.N;
         const int N = ctx.N;
-        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xstream, v, (unsigned long long)streamed, d_osrc.p, d_odst.p, d_oval.p);
+        hipStream_t xs = (chunk_no++ & 1u) ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
+        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed, d_osrc.p, d_odst.p, d_oval.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
-        HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xstream));
-        HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xstream));
+        HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
         for (int r = 0; r < R; r++) streamed_r[r] = to[r];
         streamed += M;
         return STCSP_OK;
@@ -922,7 +932,7 @@ struct stcsp_engine {
             int32_t *nc = nullptr, *nsg = nullptr;
             HIPCHK(hipHostMalloc((void **)&nc, cap * sizeof(int32_t)));
             HIPCHK(hipHostMalloc((void **)&nsg, std::max<size_t>(cap * sl, 1) * sizeof(int32_t)));
-            HIPCHK(hipStreamSynchronize(xstream));
+            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
             if (streamed_states) {
                 memcpy(nc, h_cid, (size_t)streamed_states * sizeof(int32_t));
                 memcpy(nsg, h_sig, (size_t)streamed_states * sl * sizeof(int32_t));
@@ -1070,16 +1080,31 @@ struct stcsp_engine {
     }
 
     int solve_unsharded() {
+        const bool dbg = getenv("STCSP_DEBUG") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = begin();
         if (rc != STCSP_OK) return rc;
+        const auto t1 = std::chrono::steady_clock::now();
         rc = run_rounds();
         if (rc != STCSP_OK) return rc;
-        return finish();
+        const auto t2 = std::chrono::steady_clock::now();
+        rc = finish();
+        if (dbg)
+            fprintf(stderr, "[solve] begin %.3f ms, rounds %.3f ms, finish %.3f ms\n", std::chrono::duration<double>(t1 - t0).count() * 1e3,
+                    std::chrono::duration<double>(t2 - t1).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() * 1e3);
+        return rc;
     }
 
+    unsigned long long *h_stats = nullptr;  // pinned mirror of the device statistics
+    bool stats_fresh = false;               // ... already copied by the caller (finish(): one synchronisation for everything)
     int read_counters(stcsp_counters &ctr) {
-        std::vector<unsigned long long> st(kStatSlots * kStatWords);
-        HIPCHK(hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
+        if (!stats_fresh) {
+            HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        stats_fresh = false;
+        const unsigned long long *st = h_stats;
         unsigned long long tot[kStatWords] = {0};
         for (int s = 0; s < kStatSlots; s++)
             for (int k = 0; k < kStatWords; k++) tot[k] += st[s * kStatWords + k];
@@ -1157,8 +1182,12 @@ struct stcsp_engine {
         dbg_nodes.clear();
         dbg_open.clear();
         ev_used = 0;
+        // the control block and the statistics in one go (each synchronous small copy costs ~100 us of host time)
+        if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         int rc = read_ctl();
         if (rc != STCSP_OK) return rc;
+        stats_fresh = true;
         return read_counters(snap);
     }
 
@@ -1455,6 +1484,10 @@ struct stcsp_engine {
         if (E > 0xfffffff0ull) return fail(STCSP_E_NOMEM, "edge log too large for the device export");
         if (d_alive.n < E) HIPCHK(d_alive.alloc(E + E / 4 + 256));
         if (streaming) {  // the rest of the log (the chunks before it left while the search ran)
+            if (getenv("STCSP_DEBUG")) {
+                const bool busy = hipStreamQuery(xstream) == hipErrorNotReady || hipStreamQuery(xstream2) == hipErrorNotReady;
+                fprintf(stderr, "[export] %zu of %zu edge records handed to the copy stream before the search ended (stream %s)\n", streamed, E, busy ? "still busy" : "idle");
+            }
             int rcs = stream_edges(edge_count.data(), true);
             if (rcs != STCSP_OK) return rcs;
         }
@@ -1506,7 +1539,7 @@ struct stcsp_engine {
                 if (it > (int)n_states + 8) return fail(STCSP_E_INTERNAL, "ok-fixpoint did not converge");
             }
             lap("fixpoint");
-            HIPCHK(hipStreamSynchronize(xstream));  // the last streamed chunk has landed (or nothing was streamed)
+            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }  // the last streamed chunk has landed (or nothing was streamed)
             if (streamed_is_final) {
                 live = (uint32_t)E;
                 lap("wait for the streamed chunks");
@@ -1528,7 +1561,7 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         lap("D2H result arrays");
-        HIPCHK(hipStreamSynchronize(xstream));  // cid / sig arrays complete
+        { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }  // cid / sig arrays complete
         int64_t ok_states = 0;
         for (uint32_t i = 1; i < n_states; i++) ok_states += !h_fail[i];
         ctr.dominance = (int64_t)live - ok_states;  // every ok non-root state is entered by exactly one creating leaf
