@@ -400,8 +400,16 @@ struct stcsp_engine {
         device = opt.device;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&stream));
-        HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&xstream2, hipStreamNonBlocking));
+        {
+            // lowest priority: the export must never delay the search, and streams of different priorities get
+            // different hardware queues -- with the default 4 queues per process, streams of equal priority share them
+            // round-robin with everything else the process created (torch, RCCL), and an export stream that lands in
+            // the search stream's queue serialises with the bursts of k_expand (measured: +1.5 ms per solve)
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, lo));
+            HIPCHK(hipStreamCreateWithPriority(&xstream2, hipStreamNonBlocking, lo));
+        }
         HIPCHK(hipHostMalloc((void **)&h_progress, sizeof(Progress)));
         memset(h_progress, 0, sizeof(Progress));
         HIPCHK(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
@@ -662,9 +670,11 @@ struct stcsp_engine {
         streamed = 0;
         streamed_states = 0;
         for (int r = 0; r < R; r++) streamed_r[r] = 0;
-        streaming = !sharded && !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
+        streaming = !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
+        stream_zero_copy = false;  // (measured on one GPU: 4.6 ms instead of 3.6 per solve -- the kernel then holds its wave slots at PCIe speed)
+        if (const char *zc = getenv("STCSP_STREAM_ZERO_COPY")) stream_zero_copy = atoi(zc) != 0;
         memset(h_progress, 0, sizeof(Progress));
         prog_have = false;
         prog_gen = 0;
@@ -835,6 +845,7 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     bool streaming = false;
+    bool stream_zero_copy = false;       // k_stream_edges writes the host arrays directly (no device staging, no copies)
     size_t streamed = 0;                 // edge records staged so far
     uint32_t streamed_r[R] = {0};        // ... per region of the edge log
     size_t stream_chunk_min = 32768;     // records per chunk (except the last)
@@ -910,11 +921,19 @@ struct stcsp_engine {
         v.N = ctx.N;
         const int N = ctx.N;
         hipStream_t xs = (chunk_no++ & 1u) ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
-        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed, d_osrc.p, d_odst.p, d_oval.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
-        HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
-        HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
+        if (stream_zero_copy) {
+            // experiment (STCSP_STREAM_ZERO_COPY=1): the kernel writes the pinned host arrays itself, no device staging, no copies
+            hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
+                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, h_osrc, h_odst, h_oval);
+            HIPCHK(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
+                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+            HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+            HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
+        }
         for (int r = 0; r < R; r++) streamed_r[r] = to[r];
         streamed += M;
         return STCSP_OK;
@@ -1195,8 +1214,11 @@ struct stcsp_engine {
     int expand_local(int64_t *left) {
         if (!begun) return fail(STCSP_E_STATE, "expand_local before begin");
         packed = false;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = run_rounds();
         if (rc != STCSP_OK) return rc;
+        if (getenv("STCSP_DEBUG"))
+            fprintf(stderr, "[expand_local] %.3f ms, %lld rounds so far, streamed %zu\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, levels, streamed);
         rc = read_ctl();  // outbox cursors for outbox()
         if (rc != STCSP_OK) return rc;
         host_view_fresh = true;
@@ -1624,6 +1646,43 @@ struct stcsp_engine {
             res->truncated = truncated;
             seconds_export = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (getenv("STCSP_DEBUG")) fprintf(stderr, "[export] whole export_result    %.3f ms\n", seconds_export * 1e3);
+            ctr.seconds_export = seconds_export;
+            res->counters = ctr;
+            return STCSP_OK;
+        }
+        if (sharded && streaming) {
+            // a shard's export = its states and its RAW leaf-edge log (the ok-fixpoint needs every shard's edges: it runs
+            // after the merge): exactly what the streaming export has been shipping during the supersteps
+            stcsp_counters ctr{};
+            int rcc = read_counters(ctr);
+            if (rcc != STCSP_OK) return rcc;
+            size_t E = 0;
+            for (int r = 0; r < R; r++) E += edge_count[r];
+            if (E > 0xfffffff0ull) return fail(STCSP_E_NOMEM, "edge log too large for the device export");
+            if ((rcc = stream_edges(edge_count.data(), true)) || (rcc = ensure_export_capacity(E)) || (rcc = stream_states(n_states)) || (rcc = sync_xstreams()))
+                return rcc;
+            if (streamed != E) return fail(STCSP_E_INTERNAL, "streamed %zu of %zu edge records", streamed, E);
+            r_fail.assign(n_states, 0);
+            r_issig.assign(mgr.is_sig.begin(), mgr.is_sig.end());
+            memset(res, 0, sizeof *res);
+            res->n_states = n_states;
+            res->sig_len = sl;
+            res->n_sig_vars = mgr.n_sig;
+            res->n_until = mgr.n_until;
+            res->n_until_cons = mgr.n_until_cons;
+            res->state_cid = h_cid;
+            res->state_sig = h_sig;
+            res->state_fail = r_fail.data();
+            res->n_edges = (int64_t)E;
+            res->edge_src = (const int64_t *)h_osrc;
+            res->edge_dst = (const int64_t *)h_odst;
+            res->edge_values = h_oval;
+            res->n_vars = N;
+            res->n_constraint_sets = (int32_t)mgr.sets.size();
+            res->var_is_signature = r_issig.data();
+            res->root_final = mgr.n_until_cons == 0;
+            res->truncated = truncated;
+            seconds_export = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             ctr.seconds_export = seconds_export;
             res->counters = ctr;
             return STCSP_OK;

@@ -168,7 +168,7 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
             send = torch.cat([_view(p, c * csw, device) for p, c in outs])
         recv = _exchange(send, send_counts, recv_counts, csw, comm_dev, device)
         if device.type == "cuda":
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()  # (not the whole device: the engine's export streams keep copying)
         engine.commit(recv.data_ptr() if recv.numel() else 0, sum(recv_counts))
         if nodes_recv is not None and nodes_recv.numel():
             engine.adopt(nodes_recv.data_ptr(), sum(n_recv))
