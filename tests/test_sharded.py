@@ -215,6 +215,19 @@ def test_sharded_hip_engine_one_gpu(golden, tmp_path, world, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"STCSP_STREAM_EXPORT": "0"}, {"STCSP_STREAM_CHUNK": "16"}, {"STCSP_STREAM_ZERO_COPY": "1"}],
+                         ids=["host-export", "tiny-chunks", "zero-copy"])
+def test_sharded_hip_export_paths_one_gpu(golden, tmp_path, env):
+    """A shard's export (states + RAW leaf-edge log) leaves the device during the supersteps like an unsharded
+    result does; the host-side export it replaces, chunks of 16 records and the zero-copy variant give the same merge."""
+    name = "partialorder_10"
+    r = launch(2, name, "hip", tmp_path, env=env)
+    g = golden[name]
+    assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+    assert r["dom"] == g["dom"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["juggling_b4_f5", "digitinvader3", "partialorder_12"])
 def test_sharded_pipeline_rccl_world1(golden, tmp_path, name):
     """The N>1 code path with the RCCL ("nccl") backend and device-resident candidate exchange,
