@@ -1,0 +1,45 @@
+"""Extra fuzzing on the GPU beyond the seeds the test-suite covers: engine vs the reference restatement on random models
+(tests/fuzz_models.py). usage: fuzz_more.py <first seed> <count> [prefix_k]"""
+import importlib, sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+st = importlib.import_module("stcsp-solver_amd")
+import ctypes as C  # noqa: E402
+from fuzz_models import random_model  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+_lib = C.CDLL(str(st.CSRC.parent.parent / "oracle" / "libstcsp_oracle.so"))
+st.bind_engine_api(_lib, "stcsp_oracle")
+
+
+class RefOracle(st.EngineBase):  # oracle/ref_dfs.cpp (a checker: this tool is test infrastructure, like tests/)
+    _prefix = "stcsp_oracle"
+
+    def __init__(self, model, **o):
+        super().__init__(_lib, model, **o)
+
+
+bad = checked = refused = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    text = random_model(seed)
+    m = st.Model(text=text, prefix_k=k)
+    o = RefOracle(m); ro = o.solve(); ao = o.automaton(ro); ao.traverse(); ao.renumber()
+    try:
+        e = st.Engine(m)
+    except st.StcspError as ex:
+        refused += 1
+        continue
+    re_ = e.solve(); ae = e.automaton(re_); ae.traverse(); ae.renumber()
+    ok = ae.canonical() == ao.canonical() and re_.counters.dominance == ro.counters.dominance
+    if ro.counters.fails == 0:
+        ok = ok and (re_.n_states, re_.counters.search_nodes) == (ro.n_states, ro.counters.search_nodes)
+    checked += 1
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed {seed}\n{text}", flush=True)
+    e.close(); o.close()
+    if (seed - first) % 200 == 199:
+        print(f"... {seed - first + 1} models, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"checked {checked}, refused (wide domains) {refused}, mismatches {bad}")
+sys.exit(1 if bad else 0)
