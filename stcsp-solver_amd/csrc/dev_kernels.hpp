@@ -89,8 +89,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
     // expansions, the slot goes on with the youngest sibling -- depth-first inside the slot. Whatever is left when the
     // slot stops goes to the frontier in one piece. Small rounds (fewer nodes than wavefronts, where a round is one
     // chain of dependent expansions long) get more out of each launch this way: partialorder_14 40 -> 31 rounds.
-    // Only chains of more than two expansions use it: in the big rounds (chain = 2, every slot has plenty of input
-    // nodes) parking a child in LDS for one step is pure overhead.
+    // Only chains of more than two expansions use it: parking a child in LDS for a single step is pure overhead.
     int sd = 0;
 #ifdef STCSP_PHASES
     // (hipcc 7.2 fails on this one instantiation of the instrumented build -- "Illegal instruction detected:

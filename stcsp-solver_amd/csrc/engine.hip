@@ -102,9 +102,10 @@ struct stcsp_engine {
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
     // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 8 under the general kernels
     // (expensive nodes: fewer, longer rounds -- digitinvader9 27.2 -> 23.4 ms), 4 under the LITE ones
-    // (partialorder_12/14/16 lose 3-10 % with 8). STCSP_CHAIN_SMALL / _BIG / _THRESH / _HEAVY override.
+    // (partialorder_12/14/16 lose 3-10 % with 8); chain_big 4 since the sibling stack (2 before: partialorder_18 81 -> 74.5 ms,
+    // synthetic 64 x 32 71 -> 76 M nodes/s; 6 and 8 are slower again). STCSP_CHAIN_SMALL / _BIG / _THRESH / _HEAVY override.
     bool chain_small_auto = true;
-    int chain_small = 4, chain_big = 2, chain_thresh = 65536, chain_heavy = 400000;
+    int chain_small = 4, chain_big = 4, chain_thresh = 65536, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
     DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss;
