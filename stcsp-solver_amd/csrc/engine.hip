@@ -102,7 +102,8 @@ struct stcsp_engine {
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
     // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 8 under the general kernels
     // (expensive nodes: fewer, longer rounds -- digitinvader9 27.2 -> 23.4 ms), 4 under the LITE ones
-    // (partialorder_12/14/16 lose 3-10 % with 8); chain_big 4 since the sibling stack (2 before: partialorder_18 81 -> 74.5 ms,
+    // (partialorder_12/14/16 lose 3-10 % with 8), 2 when a constraint is interpreted (the juggling _nosym instances: a few thousand
+    // uniformly expensive nodes, longer chains only serialise them: juggling_b6_f6_nosym 2.5 -> 1.8 ms); chain_big 4 since the sibling stack (2 before: partialorder_18 81 -> 74.5 ms,
     // synthetic 64 x 32 71 -> 76 M nodes/s; 6 and 8 are slower again). STCSP_CHAIN_SMALL / _BIG / _THRESH / _HEAVY override.
     bool chain_small_auto = true;
     int chain_small = 4, chain_big = 4, chain_thresh = 65536, chain_heavy = 400000;
@@ -121,6 +122,7 @@ struct stcsp_engine {
     std::vector<long long> dbg_open;
     bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true, ..>
     bool lite = false;            // no constraint needs the general wavefront revision: k_expand<.., .., .., true>
+    bool interpreted = false;     // some wavefront-revised constraint has no tuple bitmap (postfix interpreter: uniformly expensive nodes)
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
     int64_t step_max_rounds = 0, step_min_open = 0;  // expand_local budget (set_expand_budget): 0 = run the frontier dry
@@ -320,10 +322,12 @@ struct stcsp_engine {
         // forbidden set) or is the one-open-variable look-up, so the general enumeration (tuple lanes, odometer,
         // bytecode interpreter, their LDS scratch and ~25 VGPRs) is compiled out: more resident wavefronts.
         lite = true;
+        interpreted = false;
         for (const SetDesc &sd : prog.sets)
             for (int i = sd.nsmall; i < sd.nitems; i++) {
                 const ConDesc &cd = prog.cons[prog.items[sd.item_begin + i].con];
                 lite = lite && cd.bitmap_off >= 0 && cd.n_forbidden >= 0 && cd.n_forbidden <= 1;
+                interpreted = interpreted || cd.bitmap_off < 0;
             }
         if (const char *ev = getenv("STCSP_LITE")) lite = lite && atoi(ev) != 0;  // tuning switch
         const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite) * sizeof(int);
@@ -693,7 +697,7 @@ struct stcsp_engine {
         memset(h_plan, 0, sizeof(Plan));
         chunk_r = chunk_r0;
         h_plan->chunk_r = chunk_r;
-        if (chain_small_auto) chain_small = lite ? 4 : 8;
+        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 8);
         h_plan->chain_small = chain_small;
         h_plan->chain_big = chain_big;
         h_plan->chain_thresh = chain_thresh;
