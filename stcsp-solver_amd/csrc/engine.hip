@@ -184,6 +184,7 @@ struct stcsp_engine {
         if (h_fail) (void)hipHostFree(h_fail);
         if (h_miss) (void)hipHostFree(h_miss);
         if (h_stats) (void)hipHostFree(h_stats);
+        if (h_begin) (void)hipHostFree(h_begin);
         if (h_progress) (void)hipHostFree(h_progress);
         if (ev_plan) (void)hipEventDestroy(ev_plan);
         if (h_cid) (void)hipHostFree(h_cid);
@@ -707,24 +708,33 @@ struct stcsp_engine {
             // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
             // With an empty signature a leaf of set 0 must find it again, so the key is the plain
             // (tag 0); otherwise a reserved tag keeps it apart from a state with an all-zero signature.
-            std::vector<uint32_t> key(ctx.KL, 0u);
+            // (staged in pinned memory: small copies from pageable memory block the host for ~10 us each)
+            const size_t stage_words = (size_t)ctx.KL + 4 + ctx.NS;
+            if (h_begin_words < stage_words) {
+                if (h_begin) (void)hipHostFree(h_begin);
+                HIPCHK(hipHostMalloc((void **)&h_begin, stage_words * sizeof(uint32_t)));
+                h_begin_words = stage_words;
+            }
+            uint32_t *key = h_begin, *slotw = h_begin + ctx.KL, *one = slotw + 2, *node = one + 2;
+            for (int i = 0; i < ctx.KL; i++) key[i] = 0u;
             key[0] = ctx.sig_len == 0 ? 0u : kRootTag;
-            const unsigned long long h = key_hash(key.data(), ctx.KL);
+            const unsigned long long h = key_hash(key, ctx.KL);
             uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
             unsigned long long slot = ((unsigned long long)htag << 32) | 0u;
-            HIPCHK(hipMemcpyAsync(d_state_keys.p, key.data(), ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_slots.p + ((uint32_t)h & ctx.slot_mask), &slot, sizeof slot, hipMemcpyHostToDevice, stream));
-            uint32_t one = 1;
-            HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NSTATES * CST, &one, sizeof one, hipMemcpyHostToDevice, stream));
+            memcpy(slotw, &slot, sizeof slot);
+            one[0] = 1u;
+            HIPCHK(hipMemcpyAsync(d_state_keys.p, key, ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_slots.p + ((uint32_t)h & ctx.slot_mask), slotw, sizeof slot, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NSTATES * CST, one, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             n_states = 1;
             // root search node: initial domains at every point (variable.cpp:24-29), set 0
-            std::vector<uint32_t> node(ctx.NS, 0u);
+            for (int i = 0; i < ctx.NS; i++) node[i] = 0u;
             for (int p = 0; p < ctx.K; p++)
                 for (int v = 0; v < ctx.N; v++) {
                     int w = mgr.ub[v] - mgr.lb[v] + 1;
                     node[4 + p * ctx.N + v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
                 }
-            HIPCHK(hipMemcpyAsync(d_arena.p, node.data(), ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_arena.p, node, ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             h_plan->sp = 1;
             h_plan->stack[0].base = 0;
             h_plan->stack[0].cap = 1;
@@ -736,7 +746,8 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(d_plan.p, h_plan, kPlanHeader + sizeof(DevSegment), hipMemcpyHostToDevice, stream));
         int rc = push_caps();
         if (rc != STCSP_OK) return rc;
-        HIPCHK(hipStreamSynchronize(stream));
+        // (no synchronisation: everything above is ordered before the first launch on the stream, and the staging buffers
+        // are not touched again before a later call has synchronised)
         begun = true;
         t_begin = std::chrono::steady_clock::now();
         return STCSP_OK;
@@ -1119,6 +1130,8 @@ struct stcsp_engine {
         return rc;
     }
 
+    uint32_t *h_begin = nullptr;            // pinned staging of what begin() uploads (root key, its slot, the root node)
+    size_t h_begin_words = 0;
     unsigned long long *h_stats = nullptr;  // pinned mirror of the device statistics
     bool stats_fresh = false;               // ... already copied by the caller (finish(): one synchronisation for everything)
     int read_counters(stcsp_counters &ctr) {
