@@ -1206,9 +1206,19 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                 it.r2 = (int)((sw.y >> 11) & 63u);
                 it.aux = (int)sw.y >> 17;
                 it.toff = (int)sw.z;
-                // gathers are executed by every lane (cross-lane reads need the source lanes active)
-                uint32_t D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
-                uint32_t D2 = dom.gather(it.idx[2]), D3 = dom.gather(it.idx[3]);
+                // the item's domains: a gather from the registers when the block is one register per lane (one ds_bpermute
+                // each); wider blocks read the LDS copy instead (it equals `dom` between sweeps; a pass may see the
+                // prunings of the passes before it -- domains only shrink, the fixpoint is the same), which is one LDS
+                // read where a gather costs DR of them plus the selects
+                uint32_t D0, D1, D2, D3;
+                if constexpr (DR == 1) {
+                    // gathers are executed by every lane (cross-lane reads need the source lanes active)
+                    D0 = dom.gather(it.idx[0]), D1 = dom.gather(it.idx[1]);
+                    D2 = dom.gather(it.idx[2]), D3 = dom.gather(it.idx[3]);
+                } else {
+                    D0 = (uint32_t)ldom[it.idx[0]], D1 = (uint32_t)ldom[it.idx[1]];
+                    D2 = (uint32_t)ldom[it.idx[2]], D3 = (uint32_t)ldom[it.idx[3]];
+                }
                 if (isd) {
                     if (it.type == IT_NEXT) {
                         // X == next Y <=> X[p] == Y[p+1]; bit i of X is value lbX + i = bit i + sh of Y
