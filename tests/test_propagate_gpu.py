@@ -27,7 +27,7 @@ inst = importlib.import_module("stcsp-solver_amd").instances
 SYNTH_SHAPES = [(16, 8, 95, 4, 20261003), (16, 8, 88, 4, 20261003), (16, 8, 80, 4, 20261003)]
 
 
-@pytest.mark.parametrize("name", ["digitinvader6", "digitinvader9"])
+@pytest.mark.parametrize("name", ["digitinvader6", "digitinvader7", "digitinvader8", "digitinvader9"])  # every `-a` outcome the survey recorded
 def test_digitinvader_adversarial_device(stcsp, golden, name):
     g = golden[name]
     m = stcsp.Model.from_name(name)
