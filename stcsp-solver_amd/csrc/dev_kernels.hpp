@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_stream_keys(const uint32_t *keys, int K
         sig[(size_t)i * sl + (j - 1)] = (int32_t)v;
 }
 __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned long long base, unsigned long long dst_or, long long *osrc, long long *odst,
-                                                      int32_t *oval) {
+                                                      int32_t *oval, uint32_t *sdeg) {
     __shared__ unsigned long long tab[4][64];
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned lon
         tab[wib][lane] = (unsigned long long)(er - v.edges);
         osrc[base + e] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
         odst[base + e] = (long long)(dst_or | er[2]);  // sharded runs: the local index becomes a global id (rank bits)
+        if (sdeg) atomicAdd(&sdeg[er[0]], 1u);         // unsharded: out-degrees for the ok-fixpoint's first round (the global id is the local index)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -191,6 +191,8 @@ struct stcsp_engine {
         if (h_sig) (void)hipHostFree(h_sig);
         if (xstream) (void)hipStreamDestroy(xstream);
         if (xstream2) (void)hipStreamDestroy(xstream2);
+        for (int i = 0; i < 2; i++)
+            if (ev_x[i]) (void)hipEventDestroy(ev_x[i]);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -415,6 +417,8 @@ struct stcsp_engine {
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIPCHK(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, lo));
             HIPCHK(hipStreamCreateWithPriority(&xstream2, hipStreamNonBlocking, lo));
+            HIPCHK(hipEventCreateWithFlags(&ev_x[0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_x[1], hipEventDisableTiming));
         }
         HIPCHK(hipHostMalloc((void **)&h_progress, sizeof(Progress)));
         memset(h_progress, 0, sizeof(Progress));
@@ -526,6 +530,15 @@ struct stcsp_engine {
         std::swap(d_state_keys.p, nb.p);
         std::swap(d_state_keys.n, nb.n);
         ctx.state_keys = d_state_keys.p;
+        if (!sharded && d_sdeg.n < cap) {  // (the export streams were synchronised above)
+            DevBuf<uint32_t> nd;
+            HIPCHK(nd.alloc(cap));
+            HIPCHK(hipMemsetAsync(nd.p, 0, (size_t)cap * sizeof(uint32_t), stream));
+            if (d_sdeg.p && n_states) HIPCHK(hipMemcpyAsync(nd.p, d_sdeg.p, (size_t)std::min<size_t>(d_sdeg.n, n_states) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            std::swap(d_sdeg.p, nd.p);
+            std::swap(d_sdeg.n, nd.n);
+        }
         ctx.state_cap = cap;
         return STCSP_OK;
     }
@@ -681,6 +694,8 @@ struct stcsp_engine {
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
         stream_zero_copy = false;  // (measured on one GPU: 4.6 ms instead of 3.6 per solve -- the kernel then holds its wave slots at PCIe speed)
         if (const char *zc = getenv("STCSP_STREAM_ZERO_COPY")) stream_zero_copy = atoi(zc) != 0;
+        if (d_sdeg.p) HIPCHK(hipMemsetAsync(d_sdeg.p, 0, d_sdeg.n * sizeof(uint32_t), stream));
+        ev_x_used[0] = ev_x_used[1] = false;
         memset(h_progress, 0, sizeof(Progress));
         prog_have = false;
         prog_gen = 0;
@@ -854,6 +869,9 @@ struct stcsp_engine {
     // arrays and copied to the host chunk by chunk on a second stream WHILE the search runs (the copy of
     // partialorder_14's 95 MB is 1.7 ms at PCIe speed: more than a third of its whole solve when done afterwards)
     hipStream_t xstream = nullptr, xstream2 = nullptr;  // chunks alternate between the two: one transposes while the other's copies are on the link
+    hipEvent_t ev_x[2] = {nullptr, nullptr};            // ... recorded behind the last transposition kernel of each
+    bool ev_x_used[2] = {false, false};
+    DevBuf<uint32_t> d_sdeg;                            // out-degree of every state, counted by the transposition kernels as the log streams out
     unsigned chunk_no = 0;
     int sync_xstreams() {
         if (xstream) HIPCHK(hipStreamSynchronize(xstream));
@@ -931,21 +949,27 @@ struct stcsp_engine {
         }
         int rc = ensure_export_capacity(streamed + M);
         if (rc != STCSP_OK) return rc;
+        if (!sharded && d_sdeg.n < ctx.state_cap) return fail(STCSP_E_INTERNAL, "out-degree mirror smaller than the state pool");
         v.edges = d_edges.p;
         v.edge_cap = ctx.edge_cap;
         v.ES = ctx.ES;
         v.N = ctx.N;
         const int N = ctx.N;
-        hipStream_t xs = (chunk_no++ & 1u) ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
+        const int xi = (int)(chunk_no++ & 1u);
+        hipStream_t xs = xi ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
         if (stream_zero_copy) {
             // experiment (STCSP_STREAM_ZERO_COPY=1): the kernel writes the pinned host arrays itself, no device staging, no copies
             hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
-                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, h_osrc, h_odst, h_oval);
+                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, h_osrc, h_odst, h_oval, sharded ? nullptr : d_sdeg.p);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ev_x[xi], xs));
+            ev_x_used[xi] = true;
         } else {
             hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
-                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p);
+                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p, sharded ? nullptr : d_sdeg.p);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ev_x[xi], xs));
+            ev_x_used[xi] = true;
             HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
             HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
             HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
@@ -1559,11 +1583,33 @@ struct stcsp_engine {
             tA = tB;
         };
         HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
-        HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
         const unsigned eb = (unsigned)((E + 255) / 256), sb = (n_states + 255) / 256;
         uint32_t live = 0;
-        if (E) {
+        bool quick_final = false;
+        if (E && streaming && streamed == E && d_sdeg.n >= n_states) {
+            // the whole log went through the transposition kernels, which counted the out-degrees on their way: the first
+            // round of the ok-fixpoint is one pass over the states. Nobody without an out-edge (every shipped example):
+            // every logged edge is kept and the streamed arrays are the result.
+            for (int i = 0; i < 2; i++)
+                if (ev_x_used[i]) HIPCHK(hipStreamWaitEvent(stream, ev_x[i], 0));
+            hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_sdeg.p, d_fail.p, d_post.p);
+            uint32_t changed = 0;
+            HIPCHK(hipMemcpyAsync(&changed, d_post.p, sizeof changed, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            quick_final = !changed;
+            if (!quick_final) {  // somebody failed: the full fixpoint below starts from scratch
+                HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
+                HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
+            }
+            lap("first fixpoint round");
+        }
+        if (quick_final) {
+            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
+            live = (uint32_t)E;
+            lap("wait for the streamed chunks");
+        } else if (E) {
+            HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
             hipLaunchKernelGGL(k_post_outdeg, dim3(eb), dim3(256), 0, stream, v, d_outdeg.p, d_alive.p);
             bool streamed_is_final = false;
             for (int it = 0;; it++) {
@@ -1596,6 +1642,7 @@ struct stcsp_engine {
             }
         } else {
             // no edges at all: every non-root state is failed
+            HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
             hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
         }
         HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
