@@ -25,6 +25,8 @@
 #include "tree.hpp"
 
 namespace stcsp {
+static inline int neg_wrap(int x) { return (int)(0u - (unsigned)x); }  // two's-complement negation without signed overflow
+
 
 static thread_local std::string g_last_error;
 
@@ -684,12 +686,14 @@ struct Model {
         Tree *r = normalise(node->right, myLB2, myUB2);
         switch (node->token) {
             case STCSP_T_ABS:
+                // (wrapping negation: the bounds of `/` and `%` sub-terms are [INT_MIN, INT_MAX], and -INT_MIN is INT_MIN in
+                // the reference's build as well, solveralgorithm.cpp:316-322)
                 if (myLB2 < 0 && myUB2 < 0) {
-                    lb = -myUB2;
-                    ub = -myLB2;
+                    lb = neg_wrap(myUB2);
+                    ub = neg_wrap(myLB2);
                 } else if (myLB2 < 0 && myUB2 > 0) {
                     lb = 0;
-                    ub = (-myLB2 > myUB2) ? -myLB2 : myUB2;
+                    ub = (neg_wrap(myLB2) > myUB2) ? neg_wrap(myLB2) : myUB2;
                 } else {
                     lb = myLB2;
                     ub = myUB2;
