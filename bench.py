@@ -2,7 +2,10 @@
 """bench.py -- search-tree nodes/sec of the MI355X engine on partialorder_14.csp.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+N > 1 either way: under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), or plainly -- bench.py then starts its own N rank
+processes (fresh children created BEFORE this process makes any GPU call, one per LOCAL_RANK), waits for them
+and prints rank 0's line.
 
 A "step" is one complete solve of the instance as SURVEY.md section 8(d) defines the metric: from
 `solve` entry (the compiled problem is resident on the device) until the raw automaton is available
@@ -39,7 +42,56 @@ sys.path.insert(0, str(REPO))
 WORKLOAD = "partialorder_14"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SYNTH = (64, 32, 602, 6, 20261003)  # BASELINE config 4: 64 vars x |D| = 32, 602 point + 6 next table constraints
+SYNTH_SHAPE = SYNTH  # --synthetic-shape (tests shrink it: the CPU stand-in engine manages ~3 k nodes/s on 64 x 32)
 REFERENCE_P14_NODES_PER_S = 10.9e3  # the reference itself, survey VM, 1 core
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher: become the parent of N rank processes.  The parent never
+    touches the GPU (counting devices does not initialise it) and never execs: the ranks are ordinary
+    child processes; rank 0's stdout is this process's stdout.  A rank that dies takes the others with it
+    (they would wait in a collective for ever), and the exit code is the worst of the ranks'."""
+    import subprocess
+    n = args.gpus
+    if args.test_engine is None:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but this process sees {have} GPU(s)", file=sys.stderr)
+            return 2
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                LOCAL_WORLD_SIZE=str(n), STCSP_BENCH_SELF_LAUNCHED="1")
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    deadline = None
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs) and deadline is None:
+            deadline = time.time() + 20.0  # the others get a moment to fail on their own (agreed errors), then go
+        if deadline is not None and time.time() > deadline:
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.kill()  # exactly the children started above
+                    rcs[i] = pr.wait()
+        time.sleep(0.05)
+    bad = [rc for rc in rcs if rc != 0]
+    return 0 if not bad else max(abs(rc) for rc in bad) or 1
 
 
 def cpu_baseline(st, name, seconds, threads):
@@ -119,10 +171,47 @@ def other_workload(st, golden, name, device, repeats=3):
     return out
 
 
-def synthetic_workload(st, device, seconds):
+def synthetic_model(st):
+    n, d, mp, s, seed = SYNTH_SHAPE
+    return st.Model(text=st.instances.synthetic(n, d, mp, s, seed))
+
+
+def synthetic_cpu(st, seconds, threads):
+    """north_star's pair for the synthetic shape: the reference-faithful CPU restatement (oracle/ref_dfs.cpp, kind
+    "port") time-boxed on the same instance on this box's host cores -- 1 thread, then `threads` workers."""
+    lib = C.CDLL(str(REPO / "oracle" / "libstcsp_oracle.so"))
+    st.bind_engine_api(lib, "stcsp_oracle")
+    lib.stcsp_oracle_solve_parallel.argtypes = [C.c_void_p, C.c_int, C.POINTER(st.Result)]
+
+    class Ref(st.EngineBase):
+        _prefix = "stcsp_oracle"
+
+        def __init__(self, model, **o):
+            super().__init__(lib, model, **o)
+
+    m = synthetic_model(st)
+    o = Ref(m, time_limit_s=seconds)
+    t0 = time.time()
+    r = o.solve()
+    wall = time.time() - t0
+    out = {"one_core": {"nodes_per_s": r.counters.search_nodes / wall, "nodes": r.counters.search_nodes, "seconds": wall, "cores": 1},
+           "kind": "port", "note": "oracle/ref_dfs.cpp (the reference's interval propagation + DFS restated), time-boxed, same instance; "
+                                   "the reference itself reached no leaf in 25 min on this shape and prints nothing on timeout (BASELINE.md)"}
+    if threads > 1:
+        op = Ref(m, time_limit_s=seconds)
+        t0 = time.time()
+        op._check(lib.stcsp_oracle_solve_parallel(op._h, threads, C.byref(op.result)))
+        wall = time.time() - t0
+        out["all_cores"] = {"nodes_per_s": op.result.counters.search_nodes / wall, "nodes": op.result.counters.search_nodes, "seconds": wall,
+                            "cores": threads, "note": "workers share the automaton's states; this instance never leaves its root state, so the "
+                                                      "extra workers find nothing to take (the reference's unit of work is the state)"}
+    return out
+
+
+def synthetic_workload(st, device, seconds, cpu_seconds=0.0, cpu_threads=1):
     """BASELINE config 4, time-boxed (nobody reaches a leaf on this instance: SURVEY 8(d))."""
-    n, d, mp, s, seed = SYNTH
-    m = st.Model(text=st.instances.synthetic(n, d, mp, s, seed))
+    n, d, mp, s, seed = SYNTH_SHAPE
+    m = synthetic_model(st)
     e = st.Engine(m, device=device, flags=st.F_NO_EXPORT | st.F_PROFILE, time_limit_s=seconds)
     e.solve()  # the first time-boxed solve grows the frontier arena to its working size (GBs of hipMalloc + copies)
     r = e.solve()
@@ -131,12 +220,81 @@ def synthetic_workload(st, device, seconds):
     b_node = 2 * p.n_vars * p.prefix_k * 4
     out = {"shape": f"{n} vars x |D|={d}, {mp} point + {s} next table constraints, seed {seed}", "time_box_s": seconds,
            "nodes": c.search_nodes, "fails": c.fails, "leaves": c.leaves, "nodes_per_s": c.search_nodes / c.seconds_search,
-           "bytes_per_node": b_node,
+           "bytes_per_node": b_node, "item_revisions_per_node": c.revisions / max(c.search_nodes, 1),
            "k_expand_GBps": c.search_nodes * b_node / c.seconds_expand_kernel / 1e9 if c.seconds_expand_kernel > 0 else None,
            "hbm_frac": c.search_nodes * b_node / c.seconds_expand_kernel / 1e9 / HBM_PEAK_GBS if c.seconds_expand_kernel > 0 else None,
            "launch_rounds": int(c.levels)}
     e.close()
+    if cpu_seconds > 0:
+        try:
+            out["cpu_baseline"] = synthetic_cpu(st, cpu_seconds, cpu_threads)
+        except Exception as ex:  # the GPU figure must survive
+            out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
     return out
+
+
+def engine_source_sha(st):
+    """sha256 over the sources libstcsp_hip.so is built from: ties a committed PMC traffic figure to the engine it was
+    measured on (a stale profile must not decorate a changed kernel)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(st.CSRC.glob("*.hip")) + list(st.CSRC.glob("dev_*.hpp")) + [st.CSRC / "device_types.hpp", st.CSRC / "cset.cpp", st.CSRC / "cset.hpp"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def make_engine_factory(st, args, local_rank):
+    """The product engine -- or, for the launcher's CPU test only (--test-engine fmodel), the oracle's scalar frontier
+    model over gloo: that leg exists so that the N-rank launcher path can be exercised on a box without GPUs; it is
+    labelled in the output line and is never a default."""
+    if args.test_engine == "fmodel":
+        lib = C.CDLL(str(REPO / "oracle" / "libstcsp_oracle.so"))
+        st.bind_engine_api(lib, "stcsp_fmodel")
+
+        class FModel(st.EngineBase):
+            _prefix = "stcsp_fmodel"
+
+            def __init__(self, model, **o):
+                super().__init__(lib, model, **o)
+
+        return lambda model, **kw: FModel(model, **kw)
+    return lambda model, **kw: st.Engine(model, device=local_rank, **kw)
+
+
+def sharded_workload(st, sh, dist, torch, make_engine, model, rank, world, dev, label, time_limit_s=0.0, repeats=2, expect=None, knobs=None):
+    """One workload through solve_sharded on all ranks (N>1 line): whole-job nodes/s with per-rank search nodes,
+    donated / adopted open nodes, supersteps and the wall time spent in collectives."""
+    eng = make_engine(model, rank=rank, world=world, time_limit_s=time_limit_s,
+                      flags=(st.F_STEPPED if world == 1 else 0) | st.F_NO_EXPORT)
+    best = None
+    for _ in range(repeats):
+        stats = {}
+        dist.barrier()
+        t0 = time.perf_counter()
+        sh.solve_sharded(eng, rank, world, dev, stats=stats, **(knobs or {}))
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c = eng.counters()
+        mine = torch.tensor([dt, c.search_nodes, c.fails, c.leaves, stats["nodes_donated"], stats["nodes_adopted"],
+                             stats["seconds_collectives"], c.seconds_search], dtype=torch.float64, device=dev)
+        allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rows = allr.view(world, -1).tolist()
+        wall = max(r[0] for r in rows)
+        if best is None or wall < best["seconds"]:
+            nodes = int(sum(r[1] for r in rows))
+            best = {"workload": label, "seconds": wall, "nodes": nodes, "nodes_per_s": nodes / wall,
+                    "rank_search_nodes": [int(r[1]) for r in rows], "fails": int(sum(r[2] for r in rows)), "leaves": int(sum(r[3] for r in rows)),
+                    "nodes_donated": [int(r[4]) for r in rows], "nodes_adopted": [int(r[5]) for r in rows],
+                    "supersteps": stats["supersteps"], "ms_in_collectives": [r[6] * 1e3 for r in rows],
+                    "time_box_s": time_limit_s or None}
+    if expect is not None and not time_limit_s:
+        best["expected_nodes"] = expect
+        best["nodes_ok"] = best["nodes"] == expect
+    eng.close()
+    return best
 
 
 def main():
@@ -151,9 +309,23 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU leg (default: min(host cpus, 16), the box's CPU share)")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--synthetic-seconds", type=float, default=2.0)
+    ap.add_argument("--synthetic-cpu-seconds", type=float, default=5.0)
+    ap.add_argument("--synthetic-shape", default="", help="n,d,point constraints,next constraints,seed (default: BASELINE config 4 = 64,32,602,6,20261003)")
+    ap.add_argument("--scalable-workload", default="partialorder_18",
+                    help="N>1 (and --stepped) only: a second, larger instance through the sharded pipeline, outside the timed region")
+    ap.add_argument("--budget-rounds", type=int, default=8, help="sharded runs: launch rounds per superstep once a rank holds enough open nodes to share")
+    ap.add_argument("--share-per-rank", type=int, default=64, help="sharded runs: ... 'enough' = this many open nodes per rank")
     ap.add_argument("--stepped", action="store_true",
                     help="N=1 only: run the sharded pipeline (size-1 RCCL group, STCSP_F_STEPPED) -- the N>1 code path on one GPU")
+    ap.add_argument("--test-engine", choices=["fmodel"], default=None,
+                    help="tests only: drive the launcher + sharded pipeline with the oracle's CPU frontier model over gloo (no GPU)")
     args = ap.parse_args()
+
+    if args.synthetic_shape:
+        global SYNTH_SHAPE
+        SYNTH_SHAPE = tuple(int(x) for x in args.synthetic_shape.split(","))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -163,17 +335,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    cpu_test = args.test_engine is not None
+    if not cpu_test and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    stepped = world > 1 or args.stepped
+    if cpu_test:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device(f"cuda:{local_rank}")
+    stepped = world > 1 or args.stepped or cpu_test
     if stepped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cpu_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # a fresh checkout has no built libraries: rank 0 compiles them once, the others wait
     if rank == 0 and (not (st.CSRC / "libstcsp_hip.so").exists() or not (REPO / "oracle" / "libstcsp_oracle.so").exists()):
         import __graft_entry__
@@ -181,32 +360,37 @@ def main():
     if world > 1:
         dist.barrier()
 
+    make_engine = make_engine_factory(st, args, local_rank)
     model = st.Model.from_name(args.workload)
-    flags = st.F_PROFILE | (st.F_STEPPED if args.stepped and world == 1 else 0)
-    eng = st.Engine(model, device=local_rank, rank=rank, world=world, flags=flags, batch_nodes=args.batch)
+    flags = st.F_PROFILE | (st.F_STEPPED if stepped and world == 1 else 0)
+    eng = make_engine(model, rank=rank, world=world, flags=flags, batch_nodes=args.batch)
     sh = importlib.import_module("stcsp-solver_amd.sharded") if stepped else None
+    sstats = {}
+    knobs = dict(budget_rounds=args.budget_rounds, share_per_rank=args.share_per_rank)
 
     def one_step():
         """One full solve: search + ok-fixpoint + compaction + copy to the host (per shard when sharded)."""
         if not stepped:
             res = eng.solve()
             return res.counters, res
-        sh.solve_sharded(eng, rank, world, dev)
+        sh.solve_sharded(eng, rank, world, dev, stats=sstats, **knobs)
         res = eng.export()  # this shard's states and raw edges on the host (the merge on rank 0 is outside the step)
         return eng.counters(), res
 
     def barrier():
         if stepped:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
     barrier()
     t0 = time.perf_counter()
     nodes = leaves = revs = evals = wrevs = sweeps = 0
-    k_time = s_search = s_export = 0.0
+    k_time = s_search = s_export = s_coll = 0.0
     k_launches = 0
+    supersteps = donated = adopted = 0
     for _ in range(args.steps):
         c, res = one_step()
         nodes += c.search_nodes
@@ -219,16 +403,25 @@ def main():
         k_launches += c.expand_launches
         s_search += c.seconds_search
         s_export += res.counters.seconds_export
+        if stepped:
+            s_coll += sstats.get("seconds_collectives", 0.0)
+            supersteps += sstats.get("supersteps", 0)
+            donated += sstats.get("nodes_donated", 0)
+            adopted += sstats.get("nodes_adopted", 0)
     barrier()
     elapsed = time.perf_counter() - t0
     levels = c.levels
+    rank_rows = None
     if stepped:
         t = torch.tensor([elapsed, s_search], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, s_search = t.tolist()
-        t = torch.tensor([nodes, leaves], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        nodes, leaves = t.tolist()
+        mine = torch.tensor([nodes, leaves, donated, adopted, int(s_coll * 1e6)], dtype=torch.int64, device=dev)
+        allr = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rank_rows = allr.view(world, -1).tolist()
+        nodes = sum(r[0] for r in rank_rows)
+        leaves = sum(r[1] for r in rank_rows)
 
     # parity of the last timed step (outside the timed region)
     check = {}
@@ -250,30 +443,60 @@ def main():
         parity_ok = check.get("canonical_sha256") == check["golden_sha256"]
         check["ok"] = parity_ok
 
+    # N>1 (and --stepped): workloads that CAN scale, through the same sharded pipeline, outside the timed region
+    scalable = {}
+    if stepped and not args.no_other_workloads:
+        try:
+            if args.scalable_workload:
+                exp = {"partialorder_16": 6112188, "partialorder_18": 27678644}.get(args.scalable_workload)
+                scalable[args.scalable_workload] = sharded_workload(st, sh, dist, torch, make_engine, st.Model.from_name(args.scalable_workload), rank, world,
+                                                                    dev, args.scalable_workload, repeats=2, expect=exp, knobs=knobs)
+            if args.synthetic_seconds > 0:
+                n, d, mp, s_, seed = SYNTH_SHAPE
+                scalable["synthetic_64x32" if SYNTH_SHAPE == SYNTH else "synthetic"] = sharded_workload(st, sh, dist, torch, make_engine, synthetic_model(st), rank, world, dev,
+                                                               f"synthetic {n} vars x |D|={d}, {mp} + {s_} constraints, seed {seed}",
+                                                               time_limit_s=args.synthetic_seconds, repeats=2, knobs=knobs)
+        except sh.ShardedSolveError as ex:  # agreed on every rank
+            scalable["error"] = f"{type(ex).__name__}: {ex}"
+
     if rank == 0:
         S = res.sig_len
         ab, b_node, b_leaf = alg_bytes(model, S, nodes, leaves)
-        per_launch_bytes = ab / max(k_launches, 1)
+        per_launch_bytes = ab / max(k_launches * world, 1)  # (k_launches: this rank's; every rank runs its own launches)
         avg_launch_s = k_time / max(k_launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM traffic of the same kernel: FETCH_SIZE + WRITE_SIZE of every k_expand dispatch of one solve from
-        # this round's separate --pmc passes (tools/profile_r02.sh; a PMC run cannot be part of the timed
-        # bench), gfx950-corrected, per launch like `achieved`; null when no profile of this engine is committed
-        traffic = None
-        tf = REPO / "profiles" / "r02_p14_traffic.json"
+        # HBM traffic of the same kernel: FETCH_SIZE + WRITE_SIZE of every k_expand dispatch of one solve from this round's
+        # separate --pmc passes (tools/profile_r03.sh; a PMC run cannot be part of the timed bench), gfx950-corrected, per
+        # launch like `achieved`; null when the committed profile was not taken on THIS engine source (hash mismatch)
+        traffic = traffic_note = None
+        tf = REPO / "profiles" / "r03_p14_traffic.json"
         if args.workload == WORKLOAD and not stepped and tf.exists() and k_launches:
-            traffic = json.loads(tf.read_text())["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
+            tj = json.loads(tf.read_text())
+            if tj.get("engine_source_sha") == engine_source_sha(st):
+                traffic = tj["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
+                traffic_note = ("profiles/r03_p14_traffic.json (engine source sha %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                "command, gfx950-corrected, divided by this run's launches per solve" % tj["engine_source_sha"])
+            else:
+                traffic_note = f"profiles/r03_p14_traffic.json was measured on another engine source ({tj.get('engine_source_sha')}): not quoted"
         p = model.problem.contents
-        cfg = {"workload": f"{args.workload}.csp (generated by stcsp-solver_amd/instances.py; "
+        cfg = {"workload": f"{args.workload}.csp (token-identical to the reference's examples/{args.workload}.csp, regenerated by stcsp-solver_amd/instances.py; "
                            f"{p.n_vars} vars incl. aux, prefix K={p.prefix_k}, whole frontier resident in HBM)",
                "timed_region": "solve entry -> raw automaton on the host (search, with the edge log and state keys streamed to pinned host arrays "
                                "on a second stream while it runs, + ok-fixpoint + the last chunks; compaction + D2H when a state failed)",
                "nodes_per_step": nodes // args.steps, "leaves_per_step": leaves // args.steps,
                "launch_rounds_per_step": int(levels),
-               "per_node": {"item_revisions": revs / max(nodes, 1), "tuple_evaluations": evals / max(nodes, 1),
-                            "wavefront_revisions": wrevs / max(nodes, 1), "sweeps": sweeps / max(nodes, 1)},
+               "per_node": {"item_revisions": revs / max(nodes, 1) * (world if stepped else 1), "tuple_evaluations": evals / max(nodes, 1) * (world if stepped else 1),
+                            "wavefront_revisions": wrevs / max(nodes, 1) * (world if stepped else 1), "sweeps": sweeps / max(nodes, 1) * (world if stepped else 1)},
                "sharding": "none" if not stepped else f"state-owner x{world}"}
-        if world == 1 and not args.stepped and not args.no_other_workloads:
+        if cpu_test:
+            cfg["engine"] = "TEST ONLY: oracle/frontier_model.cpp over gloo (launcher / pipeline check without GPUs; not a measurement of the product)"
+        if stepped:
+            cfg["sharded"] = {"rank_search_nodes_per_step": [r[0] // args.steps for r in rank_rows],
+                              "nodes_donated": [r[2] for r in rank_rows], "nodes_adopted": [r[3] for r in rank_rows],
+                              "supersteps_per_step": supersteps / args.steps,
+                              "ms_in_collectives_per_step": [r[4] / 1e3 / args.steps for r in rank_rows],
+                              "scalable_workloads": scalable}
+        if world == 1 and not stepped and not args.no_other_workloads:
             others = {}
             for name in ("digitinvader9", "juggling_b5_f6"):
                 try:
@@ -283,12 +506,14 @@ def main():
                     others[name] = {"error": f"{type(ex).__name__}: {ex}"}
                     parity_ok = False
             try:
-                others["synthetic_64x32"] = synthetic_workload(st, local_rank, args.synthetic_seconds)
+                others["synthetic_64x32"] = synthetic_workload(st, local_rank, args.synthetic_seconds,
+                                                               0.0 if args.no_cpu_baseline else args.synthetic_cpu_seconds,
+                                                               args.cpu_threads or min(os.cpu_count() or 1, 16))
             except Exception as ex:
                 others["synthetic_64x32"] = {"error": f"{type(ex).__name__}: {ex}"}
             cfg["other_workloads"] = others
         out = {
-            "metric": "search-tree nodes/sec on partialorder_14.csp",
+            "metric": f"search-tree nodes/sec on {args.workload}.csp",
             "value": nodes / elapsed,
             "unit": "search-tree nodes/s",
             "n_gpus": world,
@@ -299,12 +524,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            "data": "reference example (regenerated)",
             "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r02_p14_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
-                                           "(tools/profile_r02.sh), gfx950-corrected, divided by this run's launches per solve" if traffic is not None else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "k_expand",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_launch_s * 1e6,
                          "launches": k_launches, "bytes_per_node": b_node, "bytes_per_leaf": b_leaf,
@@ -314,7 +537,7 @@ def main():
             "export_ms": s_export / args.steps * 1e3,
             "parity": check,
         }
-        if not args.no_cpu_baseline and world == 1 and not args.stepped:
+        if not args.no_cpu_baseline and world == 1 and not stepped:
             out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds, args.cpu_threads or min(os.cpu_count() or 1, 16))
         print(json.dumps(out), flush=True)
     if stepped:

@@ -93,16 +93,38 @@ def _exchange(send: torch.Tensor, send_counts, recv_counts, words: int, comm_dev
 
 def _exchange_sets(engine, rank: int, world: int, blob_lens, comm_dev):
     """Everyone learns every shard's constraint sets: padded all-gather of the int32 blobs."""
-    mine = torch.tensor(engine.sets_blob(), dtype=torch.int32, device=comm_dev)
-    width = max(blob_lens)
+    err = None
+    try:
+        blob = engine.sets_blob()
+    except Exception as ex:  # noqa: BLE001 -- take part in the collective first, raise afterwards (the caller agrees on it)
+        err, blob = ex, []
+    mine = torch.tensor(blob, dtype=torch.int32, device=comm_dev)
+    width = max(max(blob_lens), mine.numel(), 1)
     padded = torch.zeros(width, dtype=torch.int32, device=comm_dev)
     padded[: mine.numel()] = mine
     everyone = torch.empty(world * width, dtype=torch.int32, device=comm_dev)
     dist.all_gather_into_tensor(everyone, padded)
     everyone = everyone.cpu()
+    if err is not None:
+        raise err
     for r in range(world):
         if r != rank:
             engine.sets_import(everyone[r * width: r * width + blob_lens[r]].tolist())
+
+
+class ShardedSolveError(RuntimeError):
+    """Raised on EVERY rank of a sharded solve when any rank's engine failed (the ranks agree on the status before
+    each data exchange, so a failure never leaves the peers blocked in a collective)."""
+
+
+def _agree(ok: bool, comm_dev, what: str, local_error: Exception | None, rank: int):
+    """One tiny all-reduce(MAX) of a status word: every rank leaves with the same verdict."""
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=comm_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t.item()):
+        if local_error is not None:
+            raise ShardedSolveError(f"rank {rank}: {what} failed: {local_error}") from local_error
+        raise ShardedSolveError(f"rank {rank}: a peer failed in {what}")
 
 
 def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_through_host: bool = False,
@@ -113,34 +135,73 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
     `stage_through_host` moves the exchanges through CPU tensors (gloo with a GPU engine).
     `budget_rounds` / `share_per_rank`: expand_local hands control back after that many launch rounds
     once it holds at least share_per_rank * world open nodes (so that there is something to share).
-    Returns the number of supersteps; `stats` (optional dict) receives the redistribution totals."""
+    Returns the number of supersteps; `stats` (optional dict) receives the redistribution totals and
+    the wall time spent in collectives.
+
+    Failure protocol (a rank must never raise alone while its peers sit in a collective): every engine
+    call is caught; the error word travels with the superstep's count table (meta), with a status
+    all-reduce between `donate` and the node exchange, and with a last all-reduce after `finish` -- so
+    all ranks raise ShardedSolveError together, at the same point."""
+    import time
     csw = engine.candidate_bytes() // 4
     nsw = engine.node_bytes() // 4
-    engine.set_expand_budget(budget_rounds if world > 1 else 0, share_per_rank * world)
-    engine.begin()
     comm_dev = torch.device("cpu") if (stage_through_host or device.type == "cpu") else device
+    pending: Exception | None = None  # an engine error of this rank that the peers have not heard of yet
+    t_coll = 0.0
+
+    def guarded(fn, *a):
+        nonlocal pending
+        if pending is not None:
+            return None
+        try:
+            return fn(*a)
+        except Exception as ex:  # noqa: BLE001 -- anything: the peers must be told
+            pending = ex
+            return None
+
+    guarded(engine.set_expand_budget, budget_rounds if world > 1 else 0, share_per_rank * world)
+    guarded(engine.begin)
     # every shard starts from the same registry (the model's own sets, plus whatever earlier solves
     # on these engines exchanged), so the definitions only travel once somebody's count moves
-    last_sets = [engine.sets_count()] * world
+    last_sets = [guarded(engine.sets_count) or 0] * world
     rounds = 0
     moved = received = 0
     keep = None
-    W = world + 3  # per-rank row of the meta table: candidates per peer, open nodes, set count, set blob length
+    W = world + 4  # per-rank row of the meta table: candidates per peer, open nodes, set count, set blob length, status
     while True:
         rounds += 1
-        if rounds > max_rounds:
-            raise RuntimeError("sharded solve did not terminate")
-        left = engine.expand_local()
-        outs = [engine.outbox(p) for p in range(world)]  # (ptr, record count) per peer
-        n_sets = engine.sets_count()
-        meta = torch.tensor([c for _, c in outs] + [left, n_sets, len(engine.sets_blob())], dtype=torch.int64, device=comm_dev)
+        if rounds > max_rounds and pending is None:
+            pending = RuntimeError("sharded solve did not terminate")
+        left = guarded(engine.expand_local)
+        outs = [guarded(engine.outbox, p) for p in range(world)]  # (ptr, record count) per peer
+        n_sets = guarded(engine.sets_count)
+        blob_len = guarded(lambda: len(engine.sets_blob()))
+        if pending is not None:
+            row = [0] * world + [0, 0, 0, 1]
+        else:
+            row = [c for _, c in outs] + [left, n_sets, blob_len, 0]
+        t0 = time.perf_counter()
+        meta = torch.tensor(row, dtype=torch.int64, device=comm_dev)
         gathered = torch.empty(world * W, dtype=torch.int64, device=comm_dev)
         dist.all_gather_into_tensor(gathered, meta)
         flat = gathered.tolist()  # one device-to-host copy for the whole table
+        t_coll += time.perf_counter() - t0
         allmeta = [flat[r * W:(r + 1) * W] for r in range(world)]
+        if any(m[world + 3] for m in allmeta):
+            bad = [r for r in range(world) if allmeta[r][world + 3]]
+            if pending is not None:
+                raise ShardedSolveError(f"rank {rank}: engine failed in superstep {rounds}: {pending}") from pending
+            raise ShardedSolveError(f"rank {rank}: rank(s) {bad} failed in superstep {rounds}")
         sets_now = [m[world + 1] for m in allmeta]
         if sets_now != last_sets:  # somebody met a new constraint set: everyone learns all of them
-            _exchange_sets(engine, rank, world, [m[world + 2] for m in allmeta], comm_dev)
+            t0 = time.perf_counter()
+            err = None
+            try:
+                _exchange_sets(engine, rank, world, [m[world + 2] for m in allmeta], comm_dev)
+            except Exception as ex:  # noqa: BLE001 -- sets_import failed after the all-gather: agree below
+                err = ex
+            _agree(err is None, comm_dev, "the constraint-set exchange", err, rank)
+            t_coll += time.perf_counter() - t0
             last_sets = [engine.sets_count()] * world  # after the import every shard knows the union
         # ---- frontier redistribution (open nodes): same plan on every rank
         lefts = [m[world] for m in allmeta]
@@ -150,11 +211,20 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
         nodes_recv = None
         if any(any(row) for row in plan):
             want = sum(n_send)
-            ptr, got = engine.donate(want) if want else (0, 0)
-            if got < want:  # fewer than planned (the frontier moved on): everybody must see the same counts
-                raise RuntimeError(f"rank {rank}: planned to donate {want} open nodes, the engine had {got}")
+            err = None
+            ptr = got = 0
+            if want:
+                try:
+                    ptr, got = engine.donate(want)
+                    if got != want:  # (cannot happen: `left` counted these nodes a moment ago)
+                        raise RuntimeError(f"planned to donate {want} open nodes, the engine gave {got}")
+                except Exception as ex:  # noqa: BLE001
+                    err = ex
+            t0 = time.perf_counter()
+            _agree(err is None, comm_dev, "donate", err, rank)  # before the exchange: nobody waits for a rank that raised
             send = _view(ptr, got * nsw, device)
             nodes_recv = _exchange(send, n_send, n_recv, nsw, comm_dev, device)
+            t_coll += time.perf_counter() - t0
             moved += got
             received += sum(n_recv)
         # ---- leaf successor candidates
@@ -166,21 +236,27 @@ def solve_sharded(engine, rank: int, world: int, device: torch.device, stage_thr
             send = _view(outs[0][0], sum(send_counts) * csw, device)  # the engine packs peers back to back
         else:
             send = torch.cat([_view(p, c * csw, device) for p, c in outs])
+        t0 = time.perf_counter()
         recv = _exchange(send, send_counts, recv_counts, csw, comm_dev, device)
         if device.type == "cuda":
             torch.cuda.current_stream(device).synchronize()  # (not the whole device: the engine's export streams keep copying)
-        engine.commit(recv.data_ptr() if recv.numel() else 0, sum(recv_counts))
+        t_coll += time.perf_counter() - t0
+        # an error from here on is reported with the next superstep's meta row (or the final agreement)
+        guarded(engine.commit, recv.data_ptr() if recv.numel() else 0, sum(recv_counts))
         if nodes_recv is not None and nodes_recv.numel():
-            engine.adopt(nodes_recv.data_ptr(), sum(n_recv))
+            guarded(engine.adopt, nodes_recv.data_ptr(), sum(n_recv))
         total_open = sum(lefts)
         total_cands = sum(sum(m[:world]) for m in allmeta)
         if total_open == 0 and total_cands == 0:
             break
         keep = (recv, nodes_recv)  # the engine reads the received records asynchronously: keep them alive for the superstep
     del keep
-    engine.finish()
+    guarded(engine.finish)
+    t0 = time.perf_counter()
+    _agree(pending is None, comm_dev, "the last superstep", pending, rank)
+    t_coll += time.perf_counter() - t0
     if stats is not None:
-        stats.update(supersteps=rounds, nodes_donated=moved, nodes_adopted=received)
+        stats.update(supersteps=rounds, nodes_donated=moved, nodes_adopted=received, seconds_collectives=t_coll)
     return rounds
 
 

@@ -20,6 +20,27 @@ def load_model(st, spec, prefix_k=2):
     return st.Model.from_name(spec, prefix_k=prefix_k)
 
 
+class Faulty:
+    """Fault injection for the failure-protocol tests: the wrapped engine raises at the n-th call of one method
+    (STCSP_TEST_FAULT="method,rank[,n]"); everything else passes through."""
+
+    def __init__(self, eng, method, nth):
+        self._eng, self._method, self._nth, self._seen = eng, method, nth, 0
+
+    def __getattr__(self, name):
+        attr = getattr(self._eng, name)
+        if name != self._method:
+            return attr
+
+        def boom(*a, **k):
+            self._seen += 1
+            if self._seen >= self._nth:
+                raise RuntimeError(f"injected fault in {name}")
+            return attr(*a, **k)
+
+        return boom
+
+
 def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
     # redistribution knobs for the tests (small instances must share early to exercise the path)
     budget = dict(budget_rounds=int(os.environ.get("STCSP_TEST_BUDGET_ROUNDS", "8")),
@@ -50,6 +71,11 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
                 super().__init__(lib, model, **o)
 
         eng = FModel(m, rank=rank, world=world)
+        fault = os.environ.get("STCSP_TEST_FAULT")
+        if fault:
+            f = fault.split(",")
+            if int(f[1]) == rank:
+                eng = Faulty(eng, f[0], int(f[2]) if len(f) > 2 else 1)
         device = torch.device("cpu")
         rounds = sh.solve_sharded(eng, rank, world, device, stats=stats, **budget)
     elif backend_kind == "hip-nccl":
@@ -68,7 +94,7 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
         stepped_ms = (time.perf_counter() - t0) * 1e3
     else:
         # the real HIP engine, every shard on GPU 0, all-to-all staged through host (gloo)
-        eng = st.Engine(m, device=0, rank=rank, world=world)
+        eng = st.Engine(m, device=0, rank=rank, world=world, time_limit_s=float(os.environ.get("STCSP_TEST_TIME_LIMIT", "0")))
         device = torch.device("cuda:0")
         rounds = sh.solve_sharded(eng, rank, world, device, stage_through_host=True, stats=stats, **budget)
     # every rank's own search-node count (tensor collective)
