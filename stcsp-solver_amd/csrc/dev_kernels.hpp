@@ -343,14 +343,16 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
     // expansions per slot this round (see expand_node): a slot emits at most chain + 1 nodes and
     // chain leaves, all into one cursor region that receives from at most maxtake slots
     const int chain = taken <= (long long)p->chain_thresh ? p->chain_small : p->chain_big;
-    const unsigned out_cap = (unsigned)(chain + 2) * (unsigned)maxtake;
+    // nodes one slot may expand in the launch (= leaves, edges, new states it may produce; one more may stay alive)
+    const int proc = p->rows ? rows_processed(chain < kRowMaxChain ? chain : kRowMaxChain) : chain;
+    const unsigned out_cap = (unsigned)(proc + 2) * (unsigned)maxtake;
     int status = PS_RUN;
     if (arena_top + (unsigned long long)R * out_cap * c.NS > p->arena_words) status = PS_NEED_ARENA;
     const unsigned max_edges = (unsigned)wave_max(rl ? (int)ald(&c.ctl[L.edge0 + lane * CST]) : 0);
     const unsigned long long ns = rflu(lane == 0 ? ald(&c.ctl[L.misc0 + MISC_NSTATES * CST]) : 0u);
-    if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)chain * maxtake > p->edge_cap) status = PS_NEED_EDGES;
-    if (status == PS_RUN && ns + chain * taken > p->state_cap) status = PS_NEED_STATES;
-    if (status == PS_RUN && (ns + chain * taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
+    if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)proc * maxtake > p->edge_cap) status = PS_NEED_EDGES;
+    if (status == PS_RUN && ns + proc * taken > p->state_cap) status = PS_NEED_STATES;
+    if (status == PS_RUN && (ns + proc * taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
     if (status == PS_RUN && c.sharded) {
         int mc = 0;
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
@@ -432,7 +434,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
     const unsigned long long out_base = p->out_base, arena_words = p->arena_words, slot_cap = p->slot_cap;
     const unsigned out_cap = p->out_cap, edge_cap = p->edge_cap, state_cap = p->state_cap, cand_cap = p->cand_cap;
-    const int chunk = p->chunk_r, chain_small = p->chain_small, chain_big = p->chain_big, chain_thresh = p->chain_thresh;
+    const int chunk = p->chunk_r, chain_small = p->chain_small, chain_big = p->chain_big, chain_thresh = p->chain_thresh, rows_kernel = p->rows;
     const long long open_total = p->open_total, rounds = p->rounds;
     unsigned long long arena_top = p->arena_top;
     // ---- account the finished round (push_output)
@@ -501,14 +503,15 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
     const int maxtake = wave_max(take);
     const long long taken = wave_sum64(take);
     const int chain = taken <= (long long)chain_thresh ? chain_small : chain_big;
-    const unsigned new_cap = (unsigned)(chain + 2) * (unsigned)maxtake;
+    const int proc = rows_kernel ? rows_processed(chain < kRowMaxChain ? chain : kRowMaxChain) : chain;  // see plan_next
+    const unsigned new_cap = (unsigned)(proc + 2) * (unsigned)maxtake;
     int status = PS_RUN;
     if (arena_top + (unsigned long long)R * new_cap * c.NS > arena_words) status = PS_NEED_ARENA;
     const unsigned max_edges = (unsigned)wave_max(edges_r);
     const unsigned long long ns = rflu(ns_l);
-    if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)chain * maxtake > edge_cap) status = PS_NEED_EDGES;
-    if (status == PS_RUN && ns + chain * taken > state_cap) status = PS_NEED_STATES;
-    if (status == PS_RUN && (ns + chain * taken) * 2 > slot_cap) status = PS_NEED_TABLE;
+    if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)proc * maxtake > edge_cap) status = PS_NEED_EDGES;
+    if (status == PS_RUN && ns + proc * taken > state_cap) status = PS_NEED_STATES;
+    if (status == PS_RUN && (ns + proc * taken) * 2 > slot_cap) status = PS_NEED_TABLE;
     if (status == PS_RUN && c.sharded && (unsigned long long)wave_max(mc) + maxtake > cand_cap) status = PS_OUTBOX_FULL;
     if (status != PS_RUN) {
         if (lane == 0) p->status = status;
