@@ -343,8 +343,7 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
     // expansions per slot this round (see expand_node): a slot emits at most chain + 1 nodes and
     // chain leaves, all into one cursor region that receives from at most maxtake slots
     const int chain = taken <= (long long)p->chain_thresh ? p->chain_small : p->chain_big;
-    // nodes one slot may expand in the launch (= leaves, edges, new states it may produce; one more may stay alive)
-    const int proc = p->rows ? rows_processed(chain < kRowMaxChain ? chain : kRowMaxChain) : chain;
+    const int proc = chain;  // nodes one slot may expand in the launch (= leaves, edges, new states it may produce)
     const unsigned out_cap = (unsigned)(proc + 2) * (unsigned)maxtake;
     int status = PS_RUN;
     if (arena_top + (unsigned long long)R * out_cap * c.NS > p->arena_words) status = PS_NEED_ARENA;
@@ -434,7 +433,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
     const unsigned long long out_base = p->out_base, arena_words = p->arena_words, slot_cap = p->slot_cap;
     const unsigned out_cap = p->out_cap, edge_cap = p->edge_cap, state_cap = p->state_cap, cand_cap = p->cand_cap;
-    const int chunk = p->chunk_r, chain_small = p->chain_small, chain_big = p->chain_big, chain_thresh = p->chain_thresh, rows_kernel = p->rows;
+    const int chunk = p->chunk_r, chain_small = p->chain_small, chain_big = p->chain_big, chain_thresh = p->chain_thresh;
     const long long open_total = p->open_total, rounds = p->rounds;
     unsigned long long arena_top = p->arena_top;
     // ---- account the finished round (push_output)
@@ -503,7 +502,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
     const int maxtake = wave_max(take);
     const long long taken = wave_sum64(take);
     const int chain = taken <= (long long)chain_thresh ? chain_small : chain_big;
-    const int proc = rows_kernel ? rows_processed(chain < kRowMaxChain ? chain : kRowMaxChain) : chain;  // see plan_next
+    const int proc = chain;  // see plan_next
     const unsigned new_cap = (unsigned)(proc + 2) * (unsigned)maxtake;
     int status = PS_RUN;
     if (arena_top + (unsigned long long)R * new_cap * c.NS > arena_words) status = PS_NEED_ARENA;

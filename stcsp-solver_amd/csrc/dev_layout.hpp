@@ -53,18 +53,6 @@ struct CtlLayout {
 // bursts of rounds and synchronises once per burst.
 constexpr int kMaxSegments = 4096;
 enum PlanStatus : int { PS_RUN = 0, PS_DONE, PS_NEED_ARENA, PS_NEED_EDGES, PS_NEED_STATES, PS_NEED_TABLE, PS_HOST, PS_OUTBOX_FULL, PS_STACK_FULL };
-constexpr int kRowMaxChain = 6;   // steps per slot: bounds what is alive in a wavefront
-// k_expand_rows (dev_rows.hpp): nodes one slot's wavefront can have expanded after `chain` steps (each step expands min(alive, 4) nodes, a node leaves
-// at most two), and what is then alive (in the rows + on the stack) and goes to the frontier
-__host__ __device__ inline int rows_processed(int chain) {
-    int alive = 1, done = 0;
-    for (int s = 0; s < chain; s++) {
-        const int p = alive < 4 ? alive : 4;
-        done += p;
-        alive += p;
-    }
-    return done;
-}
 struct DevSegment {
     unsigned long long base;  // word offset into the arena
     unsigned cap;             // node slots per region
@@ -80,7 +68,6 @@ struct Plan {
     int chain;                                 // expansions per slot in the planned round
     int chain_small, chain_big, chain_thresh;  // policy: chain_small while a round has <= chain_thresh nodes
     int chain_heavy;                           // a slot stops chaining after this many cycles in one launch
-    int rows;                                  // the program runs under k_expand_rows: a slot expands up to rows_processed(chain) nodes per launch
     long long rounds, open_total;
     unsigned states_seen;   // ... and the number of states in the table then
     unsigned edge_seen[R];  // edge-log cursors at the end of the last accounted round (the host streams the log out while the search runs)

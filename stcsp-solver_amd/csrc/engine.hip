@@ -51,7 +51,6 @@
 using namespace stcsp;
 
 #include "dev_kernels.hpp"
-#include "dev_rows.hpp"
 #include "dev_postproc.hpp"
 
 using namespace stcsp::dev;
@@ -123,8 +122,6 @@ struct stcsp_engine {
     std::vector<long long> dbg_open;
     bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true, ..>
     bool lite = false;            // no constraint needs the general wavefront revision: k_expand<.., .., .., true>
-    bool rows = false;            // four nodes per wavefront, one per 16-lane row: k_expand_rows (dev_rows.hpp), for LITE programs with small blocks
-    int rows_dq = 4, rows_kt = 1; // ... its block registers per lane (N*K <= 16 dq) and key registers per lane (key words <= 16 kt)
     bool interpreted = false;     // some wavefront-revised constraint has no tuple bitmap (postfix interpreter: uniformly expensive nodes)
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
@@ -342,14 +339,7 @@ struct stcsp_engine {
             ctx.max_iw = std::max(ctx.max_iw, sd.iw);
             max_nfirst = std::max(max_nfirst, sd.nfirst);
         }
-        // four nodes per wavefront (dev_rows.hpp): LITE programs whose block, key and dirty mask fit a 16-lane row
-        // (not for sharded engines yet: a slot would emit up to rows_processed(chain) candidates, the outboxes are sized for one)
-        rows = lite && !sharded && ctx.NK <= 16 * 8 && ctx.KL <= 16 * 2 && ctx.max_iw <= kRowMaxIW && ctx.NK <= 255;
-        if (const char *ev = getenv("STCSP_ROWS")) rows = rows && atoi(ev) != 0;  // tuning / test switch
-        rows_dq = ctx.NK <= 64 ? 4 : 8;
-        rows_kt = ctx.KL <= 16 ? 1 : 2;
-        size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite) * sizeof(int);
-        if (rows) scratch = (size_t)4 * rows_wave_words(rows_dq, ctx.NS) * sizeof(int);
+        const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
@@ -369,7 +359,6 @@ struct stcsp_engine {
                 case 2: fn = expand_fn<2>(); break;
                 default: fn = expand_fn<4>(); break;
             }
-            if (rows) fn = rows_fn();
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
             if (try_prefix && e == hipSuccess && per_cu > 0) {
                 // the longest prefix of whole hot sections that costs no resident workgroup: the kernel's
@@ -396,8 +385,8 @@ struct stcsp_engine {
                 fprintf(stderr, "\n");
             }
             if (getenv("STCSP_DEBUG"))
-                fprintf(stderr, "[engine] %s%s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
-                        lite ? "LITE" : "general", rows ? " rows (4 nodes per wavefront)" : "", o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
+                fprintf(stderr, "[engine] %s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
+                        lite ? "LITE" : "general", o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
         }
         return STCSP_OK;
     }
@@ -735,7 +724,6 @@ struct stcsp_engine {
         h_plan->chain_big = chain_big;
         h_plan->chain_thresh = chain_thresh;
         h_plan->chain_heavy = chain_heavy;
-        h_plan->rows = rows ? 1 : 0;
         h_plan->world = opt.world;
         if (opt.rank == 0) {
             // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
@@ -817,36 +805,6 @@ struct stcsp_engine {
             case 6: f(std::integral_constant<int, 6>{}); break;
             default: f(std::integral_constant<int, 7>{}); break;
         }
-    }
-    // k_expand_rows<DQ, KT, L> for the program at hand
-    template <typename F>
-    void with_rows_variant(F &&f) const {
-        const int v = (rows_dq == 8 ? 4 : 0) | (rows_kt == 2 ? 2 : 0) | (img_in_lds ? 1 : 0);
-        switch (v) {
-            case 0: f(std::integral_constant<int, 0>{}); break;
-            case 1: f(std::integral_constant<int, 1>{}); break;
-            case 2: f(std::integral_constant<int, 2>{}); break;
-            case 3: f(std::integral_constant<int, 3>{}); break;
-            case 4: f(std::integral_constant<int, 4>{}); break;
-            case 5: f(std::integral_constant<int, 5>{}); break;
-            case 6: f(std::integral_constant<int, 6>{}); break;
-            default: f(std::integral_constant<int, 7>{}); break;
-        }
-    }
-    const void *rows_fn() const {
-        const void *fn = nullptr;
-        with_rows_variant([&](auto v) {
-            constexpr int V = decltype(v)::value;
-            fn = (const void *)k_expand_rows<(V & 4) ? 8 : 4, (V & 2) ? 2 : 1, (V & 1) != 0>;
-        });
-        return fn;
-    }
-    void launch_rows() {
-        const Ctx *cp = (const Ctx *)d_ctx.p;
-        with_rows_variant([&](auto v) {
-            constexpr int V = decltype(v)::value;
-            hipLaunchKernelGGL((k_expand_rows<(V & 4) ? 8 : 4, (V & 2) ? 2 : 1, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
-        });
     }
     template <int DRT>
     const void *expand_fn() const {
@@ -1100,14 +1058,11 @@ struct stcsp_engine {
                 HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
             }
             for (int k = 0; k < burst; k++) {
-                if (rows)
-                    launch_rows();
-                else
-                    switch (DR) {
-                        case 1: launch_expand<1>(); break;
-                        case 2: launch_expand<2>(); break;
-                        default: launch_expand<4>(); break;
-                    }
+                switch (DR) {
+                    case 1: launch_expand<1>(); break;
+                    case 2: launch_expand<2>(); break;
+                    default: launch_expand<4>(); break;
+                }
                 HIPCHK(hipGetLastError());
                 expand_launches++;
             }
@@ -1132,16 +1087,14 @@ struct stcsp_engine {
                 case PS_DONE:
                 case PS_OUTBOX_FULL: return STCSP_OK;
                 case PS_NEED_ARENA: {
-                    const int mc = std::max(chain_small, chain_big);
-                    const int proc = rows ? rows_processed(std::min(mc, kRowMaxChain)) : mc;  // nodes one slot may expand per launch
-                    size_t need = (size_t)h_plan->arena_top + (size_t)R * (proc + 2) * chunk_r * ctx.NS;
+                    size_t need = (size_t)h_plan->arena_top + (size_t)R * (std::max(chain_small, chain_big) + 2) * chunk_r * ctx.NS;
                     // past the soft limit an automatic batch shrinks first (deeper, narrower search:
                     // memory ~ depth x batch) and the arena only grows if that is not enough
                     while (auto_batch && need > arena_soft_words && chunk_r > 2048) {
                         chunk_r /= 2;
                         h_plan->chunk_r = chunk_r;
                         HIPCHK(hipMemcpyAsync(&d_plan.p->chunk_r, &h_plan->chunk_r, sizeof(int), hipMemcpyHostToDevice, stream));
-                        need = (size_t)h_plan->arena_top + (size_t)R * (proc + 2) * chunk_r * ctx.NS;
+                        need = (size_t)h_plan->arena_top + (size_t)R * (std::max(chain_small, chain_big) + 2) * chunk_r * ctx.NS;
                     }
                     if (need > d_arena.n && (rc = grow_arena(need))) return rc;
                     if ((rc = push_caps()) || (rc = replan())) return rc;
@@ -1179,7 +1132,7 @@ struct stcsp_engine {
         if (opt.time_limit_s > 0 && elapsed() > opt.time_limit_s) return true;
         if (opt.max_search_nodes > 0) {
             // cheap upper bound without a device read: every launch expands at most chain*R*chunk_r nodes
-            if (levels * (long long)R * chunk_r0 * (rows ? rows_processed(kRowMaxChain) : std::max(chain_small, chain_big)) >= opt.max_search_nodes) {
+            if (levels * (long long)R * chunk_r0 * std::max(chain_small, chain_big) >= opt.max_search_nodes) {
                 std::vector<unsigned long long> st(kStatSlots * kStatWords);
                 if (hipMemcpy(st.data(), d_stats.p, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                     long long nodes = 0;
