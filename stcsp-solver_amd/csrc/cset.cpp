@@ -597,6 +597,14 @@ void SetManager::build_entry(const HostCon &c, TableEntry &e) {
     e.bitmap = true;
     e.words.assign((size_t)((product + 31) / 32), 0u);
     if (product > kBitmapMaxBits) {  // the device fills it in (engine.hip: k_tabulate), then store_tabulated()
+        // k_tabulate's interpreter keeps its operand stack in 32 registers per thread: an expression that nests deeper
+        // stays interpreted by the wavefront revision (whose stack spills to LDS) instead of being tabulated wrongly
+        std::vector<int32_t> scratch;
+        int depth = 0, max_depth = 0, mask_depth = 0;
+        if (compile_expr(c.root, c.scope, tree_has_arr(c.root), scratch, depth, max_depth, mask_depth) != STCSP_OK || max_depth > kTabulateMaxStack) {
+            e = TableEntry();
+            return;
+        }
         e.pending = true;
         return;
     }

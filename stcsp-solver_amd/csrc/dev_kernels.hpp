@@ -105,7 +105,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         if (lane == 0) pos = atomicAdd(&c.ctl[L_.out(a.parity, ro)], (uint32_t)sd + extra);
         pos = rflu(pos);
         if (pos + (uint32_t)sd + extra > a.out_cap) {
-            env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
+            env.err = max(env.err, (unsigned)ERR_FLUSH_OVERFLOW);
             return false;
         }
         uint32_t *dst = out_region + (size_t)(pos + extra) * c.NS;  // [pos, pos + extra): the caller's records
@@ -310,7 +310,11 @@ __device__ __forceinline__ long long wave_sum64(long long v) { return (long long
 // Plan the next round from the top of the segment stack. Leaves status != PS_RUN when there is
 // nothing to do or the host has to act first (grow a pool, translate a constraint set, look at
 // an error).
-__device__ void plan_next(const Ctx &c, Plan *p, int lane) {
+__device__ __forceinline__ void set_gate(Plan *p, unsigned launch_id, int nslots) {
+    __hip_atomic_store(&p->gate, (unsigned long long)launch_id << 32 | (unsigned)nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// `next_launch`: id of the launch that is to execute the round planned here
+__device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch) {
     const CtlLayout L(c.world);
     const bool rl = lane < R;
     uint32_t flag = 0;
@@ -356,7 +360,7 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
         int mc = 0;
         for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
         mc = wave_max(mc);
-        if ((unsigned long long)mc + maxtake > p->cand_cap) status = PS_OUTBOX_FULL;  // a slot ends at its first leaf
+        if ((unsigned long long)mc + (unsigned long long)proc * maxtake > p->cand_cap) status = PS_OUTBOX_FULL;  // a slot may meet a leaf in every expansion of its chain
     }
     if (status != PS_RUN) {
         if (lane == 0) p->status = status;
@@ -377,6 +381,7 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane) {
         p->parity = parity;
         p->chain = chain;
         p->status = PS_RUN;
+        set_gate(p, next_launch, R * maxtake);
     }
 }
 
@@ -415,7 +420,7 @@ __device__ void push_output(const Ctx &c, Plan *p, bool consumed_input, int lane
 // every value the decision needs is requested up front -- cursors and pool fill levels by the lanes
 // that own them, the plan's scalars once -- so the common case costs two round trips. The segment
 // being consumed is known without re-reading it (plan.count holds its counts as planned).
-__device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
+__device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_launch) {
     const CtlLayout L(c.world);
     const bool rl = lane < R;
     // ---- one batch of independent loads
@@ -511,7 +516,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
     if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)proc * maxtake > edge_cap) status = PS_NEED_EDGES;
     if (status == PS_RUN && ns + proc * taken > state_cap) status = PS_NEED_STATES;
     if (status == PS_RUN && (ns + proc * taken) * 2 > slot_cap) status = PS_NEED_TABLE;
-    if (status == PS_RUN && c.sharded && (unsigned long long)wave_max(mc) + maxtake > cand_cap) status = PS_OUTBOX_FULL;
+    if (status == PS_RUN && c.sharded && (unsigned long long)wave_max(mc) + (unsigned long long)proc * maxtake > cand_cap) status = PS_OUTBOX_FULL;
     if (status != PS_RUN) {
         if (lane == 0) p->status = status;
         return;
@@ -531,11 +536,12 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane) {
         p->parity = parity;
         p->chain = chain;
         p->status = PS_RUN;
+        set_gate(p, next_launch, R * maxtake);
     }
 }
 
-__global__ void k_replan(Ctx c) {
-    if (blockIdx.x == 0 && threadIdx.x < 64) plan_next(c, c.plan, threadIdx.x);
+__global__ void k_replan(Ctx c, unsigned next_launch) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) plan_next(c, c.plan, threadIdx.x, next_launch);
 }
 // sharded commit: open an output segment of `cap` slots per region / close it again
 __global__ void k_open_segment(Ctx c, unsigned cap) {
@@ -572,12 +578,16 @@ __global__ void k_close_segment(Ctx c) {
 #define STCSP_GEN_WAVES 4
 #endif
 template <int DR, bool L, bool CS, bool LITE>
-__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp) {
+__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp, unsigned launch_id) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
+    // the planned round's gate in ONE 8-byte read (Plan::gate): is it this launch's round, and how many slots has it?
+    static_assert(offsetof(Plan, gate) == 0, "the gate is the plan's first word");
+    const unsigned long long gate = ((const __attribute__((address_space(4))) unsigned long long *)(const __attribute__((address_space(1))) unsigned long long *)c.plan)[0];
+    if ((unsigned)(gate >> 32) != launch_id) return;  // another launch's round (this workgroup is late, or the burst ran past a stop)
     if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_slots = kload(c.plan, (int)(offsetof(Plan, nslots) / 4));
+    const int n_slots = (int)(unsigned)gate;
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
     if ((int)blockIdx.x * 4 >= n_slots) return;
     const unsigned n_working = (unsigned)min((n_slots + 3) / 4, (int)gridDim.x);
@@ -639,7 +649,7 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
             __threadfence();
             const unsigned long long t_k2 = PHASE_NOW();
             (void)t_k2;
-            finalize_round(c, c.plan, lane);
+            finalize_round(c, c.plan, lane, launch_id + 1u);
 #ifdef STCSP_PHASES
             if (lane == 0) {
                 add_stats(c, 0, ST_CYC_FINAL, PHASE_NOW() - t_k2);
@@ -860,6 +870,7 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     if (co.ok && co.is_new) {
         if (lane == 0) add_stats(c, (int)(gw & 0x7fffffff), ST_NEWSTATES, 1);
         err = emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk);
+        if (err == ERR_OUT_OVERFLOW) err = ERR_COMMIT_OUT_OVERFLOW;
     }
     if (err && lane == 0) atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)err);
 }
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(256) void k_adopt(Ctx c, const uint32_t *recs, long
     if (lane == 0) np = atomicAdd(&c.ctl[L.out(p->parity, ro)], 1u);
     np = rflu(np);
     if (set < 0 || np + 1 > p->out_cap) {
-        if (lane == 0) atomicMax(&c.ctl[L.misc0 + MISC_ERROR * CST], (uint32_t)(set < 0 ? ERR_UNKNOWN_SET : ERR_OUT_OVERFLOW));
+        if (lane == 0) atomicMax(&c.ctl[L.misc0 + MISC_ERROR * CST], (uint32_t)(set < 0 ? ERR_UNKNOWN_SET : ERR_ADOPT_OVERFLOW));
         return;
     }
     uint32_t *dst = c.arena + p->out_base + ((size_t)ro * p->out_cap + np) * c.NS;
@@ -974,7 +985,8 @@ __global__ __launch_bounds__(256) void k_tabulate(TabArgs a, uint32_t *bitmap) {
                 rem = q;
             }
     }
-    int stk[32];
+    int stk[kTabulateMaxStack];  // (cset.cpp build_entry leaves deeper programs to the interpreter of the wavefront revision)
+    static_assert(kTabulateMaxStack == 32, "the stack indices below wrap at 32");
     int sp = 0, tos = 0;
     bool valid = true;
     uint32_t dead = 0;

@@ -60,6 +60,12 @@ struct DevSegment {
     int pad;
 };
 struct Plan {
+    // Gate of the planned round: (id of the ONE launch that may execute it) << 32 | its number of slots, written and read
+    // as one 8-byte word. A launch is dealt more workgroups than a small round has slots; such a surplus workgroup may be
+    // scheduled late -- when the GPU is shared with another process, or busy with the export streams, AFTER the last
+    // working workgroup of its launch has planned the next round. It must not mistake that plan for its own: it then
+    // reads either the old gate (no slot for it: leaves) or the new one (another launch's id: leaves).
+    unsigned long long gate;
     int status, parity, nslots, sp;
     int take[R], count[R];
     unsigned long long in_base, out_base, arena_top, arena_words, slot_cap;
@@ -75,7 +81,8 @@ struct Plan {
 };
 enum { MISC_NSTATES = 0, MISC_NMISS = 1, MISC_ERROR = 2 };
 enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OVERFLOW = 4, ERR_UNKNOWN_SET = 5,
-       ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8 };
+       ERR_EMPTY_DOMAIN = 6, ERR_OUT_OVERFLOW = 7, ERR_CAND_OVERFLOW = 8,
+       ERR_ADOPT_OVERFLOW = 9, ERR_COMMIT_OUT_OVERFLOW = 10, ERR_FLUSH_OVERFLOW = 11 };
 
 // Progress mirror in pinned HOST memory (streaming export): finalize_round of launch g writes the edge-log cursors and
 // the state count as of the end of launch g, each word tagged with g (high half), so the host can ship finished parts

@@ -30,6 +30,7 @@ constexpr unsigned long long kBudgetCodeIters = 32;      // ... and an interpret
 constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
 constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap the HOST tabulates per constraint (~0.1 us per tuple)
+constexpr int kTabulateMaxStack = 32;        // operand-stack entries of k_tabulate's per-thread interpreter (deeper programs are not tabulated on the device)
 constexpr long long kBitmapMaxBitsDevice = 1ll << 28;  // ... and the largest one at all: bigger ones up to here are tabulated on the device
 
 enum ConType : int32_t { CT_NEXT = 0, CT_POINT = 1, CT_UNTIL = 2, CT_AT = 3 };

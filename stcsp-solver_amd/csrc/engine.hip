@@ -496,9 +496,6 @@ struct stcsp_engine {
         rc = alloc_edges(small_pools ? 8u : 1u << 15);
         if (rc != STCSP_OK) return rc;
         // outbox: [owner][region] x cand_cap records. Unsharded: emptied after every launch.
-        cand_cap = (uint32_t)(sharded ? std::max(4 * chunk_r, 4096) : 64);
-        HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
-        if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         // arena of node segments (grown on demand)
         HIPCHK(d_arena.alloc(small_pools ? (size_t)4 * R * ctx.NS : std::min((size_t)8 * R * chunk_r * ctx.NS, std::max(arena_soft_words, (size_t)64 * R * ctx.NS))));
         HIPCHK(d_plan.alloc(1));
@@ -515,6 +512,12 @@ struct stcsp_engine {
         if (const char *ev = getenv("STCSP_CHAIN_THRESH")) chain_thresh = std::max(0, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_HEAVY")) chain_heavy = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_DEBUG")) dbg_rounds = atoi(ev) >= 2;
+        // outbox: [owner][region] x cand_cap records. Unsharded: unused. A slot may meet a leaf in every expansion of its
+        // chain, so a region of an owner's outbox receives up to chain x max-take candidates per launch: an EMPTY outbox
+        // must hold one launch (or the planner would report PS_OUTBOX_FULL for ever).
+        cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * chunk_r, 4096) : 64);
+        HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
+        if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         sync_ctx();
         return STCSP_OK;
     }
@@ -679,8 +682,9 @@ struct stcsp_engine {
         prog_gen = g;
         return STCSP_OK;
     }
+    unsigned launch_seq = 0;  // id of the next k_expand launch (Plan::gate)
     int replan() {
-        hipLaunchKernelGGL(k_replan, dim3(1), dim3(64), 0, stream, ctx);
+        hipLaunchKernelGGL(k_replan, dim3(1), dim3(64), 0, stream, ctx, launch_seq);
         HIPCHK(hipGetLastError());
         return STCSP_OK;
     }
@@ -784,8 +788,9 @@ struct stcsp_engine {
         uint32_t e = h_ctl[L.misc0 + MISC_ERROR * CST];
         if (e) {
             static const char *names[] = {"", "watchdog", "table spin", "edge overflow", "state overflow", "unknown set",
-                                          "empty domain", "frontier overflow", "candidate overflow"};
-            return fail(e == ERR_WATCHDOG ? STCSP_E_INTERNAL : STCSP_E_NOMEM, "device reported error %u (%s)", e, e < 9 ? names[e] : "?");
+                                          "empty domain", "frontier overflow", "candidate overflow",
+                                          "frontier overflow in adopt", "frontier overflow in commit", "frontier overflow at a slot's end"};
+            return fail(e == ERR_WATCHDOG ? STCSP_E_INTERNAL : STCSP_E_NOMEM, "device reported error %u (%s)", e, e < 12 ? names[e] : "?");
         }
         return STCSP_OK;
     }
@@ -820,7 +825,7 @@ struct stcsp_engine {
         const Ctx *cp = (const Ctx *)d_ctx.p;
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
-            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp);
+            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, launch_seq++);
         });
     }
 

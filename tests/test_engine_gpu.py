@@ -252,3 +252,42 @@ def test_engine_batch_shrinks_at_arena_soft_limit(stcsp, golden, monkeypatch):
     ru = stcsp.Engine(big).solve()
     assert (rl.counters.search_nodes, rl.n_states) == (ru.counters.search_nodes, ru.n_states) == (6112188, 130048)
     assert ru.counters.levels < rl.counters.levels
+
+
+# ---- device tabulation (k_tabulate): constraints whose tuple space is too big for the host (2^22 .. 2^28 tuples)
+# Eight variables over [0,7] = 2^24 tuples of the initial product (what the bitmap is tabulated over); six unary
+# constraints keep the search at 2^6 * 8 * 8 leaves so that the reference-faithful oracle finishes in seconds.
+TAB_HEAD = "".join(f"var x{i} : [0, 7];\n" for i in range(8)) + "arr T : {3, 1, 4, 1, 5, 9, 2, 6};\n" + \
+           "".join(f"x{i} < 2;\n" for i in range(1, 7))
+TAB_ARR_IF = TAB_HEAD + "T[x0 + x1 * 7] + (if (x1 gt x2) then (x3 + x7) else (x4 - x7)) + x5 * x6 - x7 >= 2;\n"  # x0 + 7 x1 leaves the array for x1 = 1, x0 > 0
+
+
+def deep_sum(depth):
+    """x0 + (x1 + (x2 + ... )) nested `depth` levels: the postfix program needs an operand stack of depth + 1."""
+    expr = "x7"
+    for k in range(depth):
+        expr = f"x{k % 7} + ({expr})"
+    return expr
+
+
+TAB_DEEP = TAB_HEAD + f"{deep_sum(36)} >= 6;\n"
+
+
+@pytest.mark.parametrize("text,label", [(TAB_ARR_IF, "array + if"), (TAB_DEEP, "operand stack deeper than k_tabulate's 32 registers")])
+def test_device_tabulated_bitmap_equals_host_evaluation_and_oracle(stcsp, RefOracle, monkeypatch, text, label):
+    """k_tabulate ran deep programs on a wrapping 32-entry stack, and nothing compared a device-
+    tabulated bitmap (incl. the array / `valid` path) with the host evaluator. Same model three ways: device tabulation
+    on, device tabulation off (the constraint is interpreted by the wavefront revision), reference-faithful oracle."""
+    m = stcsp.Model(text=text)
+    o = RefOracle(m)
+    ao, _ = finish(o, o.solve())
+    shas = {}
+    for tab in ("1", "0"):
+        monkeypatch.setenv("STCSP_DEVICE_TABULATE", tab)
+        e = stcsp.Engine(m)
+        r = e.solve()
+        a, _ = finish(e, r)
+        shas[tab] = a.canonical_sha256()
+        assert a.canonical() == ao.canonical(), f"{label}: STCSP_DEVICE_TABULATE={tab}"
+        e.close()
+    assert shas["1"] == shas["0"]
