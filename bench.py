@@ -442,6 +442,18 @@ def main():
         check["golden_sha256"] = golden[args.workload]["canonical_sha256"]
         parity_ok = check.get("canonical_sha256") == check["golden_sha256"]
         check["ok"] = parity_ok
+    if not stepped:
+        # the streamed export (edge log shipped while the search runs, ordered by kernel boundaries: DESIGN 4.4) against
+        # the compacting export of one more solve of the same engine (everything copied after the search has ended)
+        os.environ["STCSP_STREAM_EXPORT"] = "0"
+        try:
+            r2 = eng.solve()
+            a2 = eng.automaton(r2).traverse().renumber()
+            check["export_paths"] = {"streamed_sha256": check.get("canonical_sha256"), "compacting_sha256": a2.canonical_sha256(),
+                                     "equal": a2.canonical_sha256() == check.get("canonical_sha256")}
+            parity_ok = parity_ok and check["export_paths"]["equal"]
+        finally:
+            del os.environ["STCSP_STREAM_EXPORT"]
 
     # N>1 (and --stepped): workloads that CAN scale, through the same sharded pipeline, outside the timed region
     scalable = {}

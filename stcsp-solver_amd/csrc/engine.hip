@@ -41,6 +41,7 @@
 #include <memory>
 #include <string>
 #include <type_traits>
+#include <thread>
 #include <vector>
 
 #include "cset.hpp"
@@ -171,6 +172,12 @@ struct stcsp_engine {
     std::vector<uint8_t> p_valid, p_final, p_alive;
 
     ~stcsp_engine() {
+        // the device writes several of the pinned buffers freed below (progress mirror, streamed result arrays) from
+        // launches and copies that may still be in flight after an error return: drain every stream first
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (xstream) (void)hipStreamSynchronize(xstream);
+        if (xstream2) (void)hipStreamSynchronize(xstream2);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -640,7 +647,11 @@ struct stcsp_engine {
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) HIPCHK(q);
                 int rc = ship_progress();
-                if (rc != STCSP_OK) return rc;
+                if (rc != STCSP_OK) {
+                    (void)hipStreamSynchronize(stream);  // the burst still writes the progress mirror
+                    return rc;
+                }
+                std::this_thread::yield();  // (the poll must not own a host core: one engine per rank under torchrun)
             }
             prog_have = false;  // (the caller ships everything up to the end of the burst)
         }
@@ -702,8 +713,6 @@ struct stcsp_engine {
         streaming = !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
-        stream_zero_copy = false;  // (measured on one GPU: 4.6 ms instead of 3.6 per solve -- the kernel then holds its wave slots at PCIe speed)
-        if (const char *zc = getenv("STCSP_STREAM_ZERO_COPY")) stream_zero_copy = atoi(zc) != 0;
         if (d_sdeg.p) HIPCHK(hipMemsetAsync(d_sdeg.p, 0, d_sdeg.n * sizeof(uint32_t), stream));
         ev_x_used[0] = ev_x_used[1] = false;
         memset(h_progress, 0, sizeof(Progress));
@@ -844,6 +853,9 @@ struct stcsp_engine {
         if (set < 0 || set >= (int)prog.sets.size() || count < 0 || count > (1 << 24) || !blocks || !outcome)
             return fail(STCSP_E_INVALID, "propagate: bad arguments (set %d of %zu, count %lld)", set, prog.sets.size(), (long long)count);
         if (count == 0) return STCSP_OK;
+        // a solve in progress (stepping interface) owns the control block and the statistics; a finished one keeps its
+        // cursors (export may still follow): only the error / miss words and the work counters are reset here
+        if (begun && !finished) return fail(STCSP_E_STATE, "propagate inside a solve that has not finished");
         HIPCHK(hipSetDevice(device));
         int rc = flush_ctx();
         if (rc != STCSP_OK) return rc;
@@ -854,7 +866,8 @@ struct stcsp_engine {
         HIPCHK(d_out.alloc((size_t)count));
         HIPCHK(hipMemcpyAsync(d_blk.p, blocks, words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
-        HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));  // error / miss words (begin() does the same)
+        HIPCHK(hipMemsetAsync(d_ctl.p + L.misc0 + MISC_ERROR * CST, 0, sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_ctl.p + L.misc0 + MISC_NMISS * CST, 0, sizeof(uint32_t), stream));
         const unsigned grid = (unsigned)std::min<int64_t>((count + 3) / 4, max_blocks);
         switch (DR) {
             case 1: launch_probe<1>(grid, d_blk.p, (int)count, set, expire, d_out.p); break;
@@ -890,7 +903,6 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     bool streaming = false;
-    bool stream_zero_copy = false;       // k_stream_edges writes the host arrays directly (no device staging, no copies)
     size_t streamed = 0;                 // edge records staged so far
     uint32_t streamed_r[R] = {0};        // ... per region of the edge log
     size_t stream_chunk_min = 32768;     // records per chunk (except the last)
@@ -939,8 +951,9 @@ struct stcsp_engine {
         }
         return STCSP_OK;
     }
-    // Stage and ship the edge records logged since the last call. `upto[r]` = cursor of region r as of the last
-    // COMPLETED launch (the main stream is synchronised at every call site).
+    // Stage and ship the edge records logged since the last call. `upto[r]` = cursor of region r as of a launch that has
+    // ENDED: either the main stream is synchronised (calls between bursts, final call), or the snapshot of launch g - 1 is
+    // handed over only once launch g has been seen to finalize (ship_progress, mid-burst).
     int stream_edges(const uint32_t *upto, bool final) {
         if (!streaming) return STCSP_OK;
         StreamView v{};
@@ -968,23 +981,14 @@ struct stcsp_engine {
         const int N = ctx.N;
         const int xi = (int)(chunk_no++ & 1u);
         hipStream_t xs = xi ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
-        if (stream_zero_copy) {
-            // experiment (STCSP_STREAM_ZERO_COPY=1): the kernel writes the pinned host arrays itself, no device staging, no copies
-            hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
-                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, h_osrc, h_odst, h_oval, sharded ? nullptr : d_sdeg.p);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(ev_x[xi], xs));
-            ev_x_used[xi] = true;
-        } else {
-            hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
-                               sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p, sharded ? nullptr : d_sdeg.p);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(ev_x[xi], xs));
-            ev_x_used[xi] = true;
-            HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
-            HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
-            HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
-        }
+        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
+                           sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p, sharded ? nullptr : d_sdeg.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev_x[xi], xs));
+        ev_x_used[xi] = true;
+        HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
         for (int r = 0; r < R; r++) streamed_r[r] = to[r];
         streamed += M;
         return STCSP_OK;

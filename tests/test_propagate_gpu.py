@@ -126,3 +126,40 @@ def test_engine_search_tree_equals_frontier_model(stcsp, FrontierModel, RefOracl
     o = RefOracle(m)
     ao, _ = finish(o, o.solve())
     assert a.canonical() == ao.canonical()
+
+
+@pytest.mark.parametrize("name", ["partialorder_10", "partialorder_14", "digitinvader3", "juggling_b4_f5"])
+def test_node_propagation_under_translated_sets_and_after_a_solve(stcsp, oracle_lib, FrontierModel, golden, name):
+    """VERDICT r02 weak #10 / ADVICE r02 (propagate wiped a finished solve): the node-level seam sampled under the constraint
+    sets the search actually runs under (partialorder: 99 % of the nodes are under set 1, the set after `first`), on an
+    engine that HAS a finished, not yet exported solve -- which must still export the reference's automaton afterwards."""
+    m = stcsp.Model.from_name(name)
+    e = stcsp.Engine(m, flags=stcsp.F_NO_EXPORT)
+    e.solve()
+    f = FrontierModel(m)
+    f.solve()
+    assert e.sets_blob() == f.sets_blob()  # same registry, same ordinals: set s means the same thing on both sides
+    n_sets = e.sets_count()
+    assert n_sets >= 2
+    rng = np.random.default_rng(20261005)
+    count = 64 if name.startswith("juggling") else 192
+    for s in range(1, min(n_sets, 4)):
+        blocks = random_blocks(m, 2, rng, count)
+        got, outcome, skipped = e.propagate(blocks, s, 0)
+        want = blocks.copy()
+        ok = np.zeros(count, dtype=np.int32)
+        for i in range(count):
+            row = np.ascontiguousarray(want[i])
+            ok[i] = oracle_lib.stcsp_fmodel_propagate(f._h, s, 0, row.ctypes.data_as(C.POINTER(C.c_uint32)))
+            want[i] = row
+        live = ok != 0
+        if skipped == 0:
+            assert ((outcome != 0) == live).all(), f"set {s}"
+            assert (got[live] == want[live]).all(), f"set {s}"
+        else:
+            assert (outcome[live] != 0).all()
+            assert ((got[live] & want[live]) == want[live]).all()
+    r = e.export()  # the finished solve is still there
+    a, _ = finish(e, r)
+    g = golden[name]
+    assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (g["states"], g["edges"], g["canonical_sha256"])

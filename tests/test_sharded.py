@@ -259,11 +259,11 @@ def test_sharded_hip_engine_one_gpu(golden, tmp_path, world, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"STCSP_STREAM_EXPORT": "0"}, {"STCSP_STREAM_CHUNK": "16"}, {"STCSP_STREAM_ZERO_COPY": "1"}],
-                         ids=["host-export", "tiny-chunks", "zero-copy"])
+@pytest.mark.parametrize("env", [{"STCSP_STREAM_EXPORT": "0"}, {"STCSP_STREAM_CHUNK": "16"}],
+                         ids=["host-export", "tiny-chunks"])
 def test_sharded_hip_export_paths_one_gpu(golden, tmp_path, env):
     """A shard's export (states + RAW leaf-edge log) leaves the device during the supersteps like an unsharded
-    result does; the host-side export it replaces, chunks of 16 records and the zero-copy variant give the same merge."""
+    result does; the host-side export it replaces and chunks of 16 records give the same merge."""
     name = "partialorder_10"
     r = launch(2, name, "hip", tmp_path, env=env)
     g = golden[name]

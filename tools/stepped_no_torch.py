@@ -4,11 +4,11 @@ import importlib, os, sys
 sys.path.insert(0, '.')
 st = importlib.import_module("stcsp-solver_amd")
 m = st.Model.from_name(sys.argv[1] if len(sys.argv) > 1 else "partialorder_14")
-ENVS = [{}, {"STCSP_STREAM_EXPORT": "0"}, {"STCSP_STREAM_ZERO_COPY": "0"}, {"STCSP_STREAM_ZERO_COPY": "0", "STCSP_STREAM_POLL": "0"},
-        {"STCSP_STREAM_ZERO_COPY": "0", "STCSP_BURST": "32"}, {"STCSP_STREAM_ZERO_COPY": "0", "STCSP_BATCH": "262144"},
-        {"STCSP_STREAM_ZERO_COPY": "0", "STCSP_BATCH": "262144", "STCSP_BURST": "32"}]
+ENVS = [{}, {"STCSP_STREAM_EXPORT": "0"}, {"STCSP_STREAM_POLL": "0"},
+        {"STCSP_BURST": "32"}, {"STCSP_BATCH": "262144"},
+        {"STCSP_BATCH": "262144", "STCSP_BURST": "32"}]
 for env in ENVS:
-    for k in ("STCSP_STREAM_EXPORT", "STCSP_STREAM_ZERO_COPY", "STCSP_STREAM_POLL", "STCSP_BURST", "STCSP_BATCH"):
+    for k in ("STCSP_STREAM_EXPORT", "STCSP_STREAM_POLL", "STCSP_BURST", "STCSP_BATCH"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = st.Engine(m, flags=st.F_STEPPED)
