@@ -136,9 +136,21 @@ void SetManager::finish_set(HostSet &s) {
     s.self_loop = !any_first_or_at;
 }
 
+static uint64_t set_content_hash(const HostSet &s) {
+    std::vector<int32_t> words;
+    for (auto &c : s.cons) serialise_tree(c.root, words);
+    uint64_t h = 1469598103934665603ull;
+    for (int32_t w : words) {
+        h ^= (uint32_t)w;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
 int SetManager::register_set(std::unique_ptr<HostSet> s) {
     finish_set(*s);
     int idx = (int)sets.size();
+    set_by_hash.emplace(set_content_hash(*s), idx);
     if (sharded) {
         std::vector<int32_t> words;
         for (auto &c : s->cons) serialise_tree(c.root, words);
@@ -266,9 +278,12 @@ int SetManager::transition(int set, const std::vector<int> &first_vals) {
         int rc = push_constraint(*ns, t);
         if (rc != STCSP_OK) return rc;
     }
-    int found = -1;
-    for (size_t i = 0; i < sets.size() && found < 0; i++)
-        if (set_eq(*ns, *sets[i])) found = (int)i;
+    int found = -1;  // seenConstraints lookup (solveralgorithm.cpp:786-800): structural equality, found through a content hash
+    {
+        auto range = set_by_hash.equal_range(set_content_hash(*ns));
+        for (auto it2 = range.first; it2 != range.second; ++it2)
+            if (set_eq(*ns, *sets[it2->second]) && (found < 0 || it2->second < found)) found = it2->second;
+    }
     if (found < 0) {
         found = register_set(std::move(ns));
         if (found < 0) return found;
@@ -282,46 +297,79 @@ int SetManager::pretranslate(long long max_tuples, int max_sets) {
     for (size_t si = 0; si < sets.size() && (int)sets.size() < max_sets; si++) {  // sets.size() grows while we go
         if (sets[si]->self_loop) continue;
         const std::vector<int> fv = sets[si]->first_vars;  // (copy: sets may be re-allocated by transition())
-        long long tuples = 1;
-        for (int v : fv) {
-            tuples *= (long long)ub[v] - lb[v] + 1;
-            if (tuples > max_tuples) break;
-        }
-        if (tuples > max_tuples) continue;
-        std::vector<int> vals(fv.size());
-        for (size_t k = 0; k < fv.size(); k++) vals[k] = lb[fv[k]];
-        for (;;) {
-            // a tuple that violates one of the set's own `first` constraints is never seen at a leaf (the constraint
-            // is enforced at time 0): its translation -- a set with a false constant constraint -- is not worth a set
-            bool reachable = true;
-            {
-                std::map<int, int> vm;
-                for (size_t k = 0; k < fv.size(); k++) vm[fv[k]] = vals[k];
-                HostSet scratch;
+        // Values a leaf can show for each captured variable: a `first` constraint over ONE captured variable and nothing
+        // else (first giveTo < 2; first seen3 == 0) is enforced at time 0, so only the values it admits are ever
+        // captured -- partialorder_14's 458,752 tuples shrink to 2.
+        std::vector<std::vector<int>> cand(fv.size());
+        long long full = 1, tuples = 1;
+        for (size_t k = 0; k < fv.size(); k++) {
+            const int v = fv[k];
+            full *= (long long)ub[v] - lb[v] + 1;
+            if (full > kDirectTransMax) full = kDirectTransMax + 1;
+            for (int x = lb[v]; x <= ub[v]; x++) {
+                bool ok = true;
                 for (auto &c : sets[si]->cons) {
-                    if (!c.has_first) continue;
+                    if (!c.has_first || !ok) continue;
+                    std::set<int> cf;
+                    collect_first_vars(c.root, false, cf);
+                    if (cf.size() != 1 || *cf.begin() != v) continue;
+                    std::vector<int> all;
+                    collect_scope(c.root, all);  // every variable of the tree, captured or not
+                    if (all.size() != 1) continue;
+                    HostSet scratch;
+                    std::map<int, int> vm;
+                    vm[v] = x;
                     Tree *t = translate(scratch, c.root, vm);
                     std::vector<int> sc;
                     collect_scope(t, sc);
-                    if (sc.empty() && !is_tautology(t, arrays)) reachable = false;
+                    if (sc.empty() && !is_tautology(t, arrays)) ok = false;
                 }
+                if (ok) cand[k].push_back(x);
             }
-            if (reachable && !sets[si]->trans.count(vals)) {
-                const int ns = transition((int)si, vals);
-                if (ns < 0) return ns;
-                added++;
-                if ((int)sets.size() >= max_sets) return added;
-            }
-            size_t k = 0;  // next tuple (odometer)
-            for (; k < fv.size(); k++) {
-                if (vals[k] < ub[fv[k]]) {
-                    vals[k]++;
-                    break;
-                }
-                vals[k] = lb[fv[k]];
-            }
-            if (k == fv.size()) break;
+            tuples *= (long long)cand[k].size();
+            if (tuples > max_tuples) break;
         }
+        if (tuples > max_tuples) continue;
+        if (tuples > 0) {
+            std::vector<size_t> pos(fv.size(), 0);
+            std::vector<int> vals(fv.size());
+            for (;;) {
+                for (size_t k = 0; k < fv.size(); k++) vals[k] = cand[k][pos[k]];
+                // a tuple that violates one of the set's own `first` constraints is never seen at a leaf (the constraint
+                // is enforced at time 0): its translation -- a set with a false constant constraint -- is not worth a set
+                bool reachable = true;
+                {
+                    std::map<int, int> vm;
+                    for (size_t k = 0; k < fv.size(); k++) vm[fv[k]] = vals[k];
+                    HostSet scratch;
+                    for (auto &c : sets[si]->cons) {
+                        if (!c.has_first) continue;
+                        Tree *t = translate(scratch, c.root, vm);
+                        std::vector<int> sc;
+                        collect_scope(t, sc);
+                        if (sc.empty() && !is_tautology(t, arrays)) reachable = false;
+                    }
+                }
+                if (reachable && !sets[si]->trans.count(vals)) {
+                    const int ns = transition((int)si, vals);
+                    if (ns < 0) return ns;
+                    added++;
+                    if ((int)sets.size() >= max_sets) return added;
+                }
+                size_t k = 0;  // next tuple (odometer)
+                for (; k < fv.size(); k++) {
+                    if (pos[k] + 1 < cand[k].size()) {
+                        pos[k]++;
+                        break;
+                    }
+                    pos[k] = 0;
+                }
+                if (k == fv.size()) break;
+            }
+        }
+        // every tuple a leaf can show has its transition: the device looks it up in a table indexed by the tuple (when the
+        // FULL space is small enough for a table; else in the list, which then holds the reachable tuples only)
+        sets[si]->direct = full <= kDirectTransMax;
     }
     return added;
 }
@@ -662,12 +710,36 @@ int SetManager::compile(FlatProgram &out) {
         }
         sd.first_off = (int32_t)out.firstvars.size();
         out.firstvars.insert(out.firstvars.end(), s.first_vars.begin(), s.first_vars.end());
-        sd.trans_begin = (int32_t)out.trans.size();
-        sd.trans_count = (int32_t)s.trans.size();
-        for (auto &kv : s.trans) {
-            TransDesc td{(int32_t)out.transvals.size(), kv.second};
-            out.transvals.insert(out.transvals.end(), kv.first.begin(), kv.first.end());
-            out.trans.push_back(td);
+        {
+            int32_t st = 1;  // mixed radix over the captured variables, first one fastest
+            for (int v : s.first_vars) {
+                out.fstrides.push_back(st);
+                st *= ub[v] - lb[v] + 1;
+            }
+        }
+        if (s.direct) {
+            // transition table indexed by the captured tuple (-1: no leaf can have it, or not translated yet -> the host is asked)
+            long long tuples = 1;
+            for (int v : s.first_vars) tuples *= (long long)ub[v] - lb[v] + 1;
+            sd.trans_begin = (int32_t)out.tdirect.size();
+            sd.trans_count = -1;
+            out.tdirect.resize(out.tdirect.size() + (size_t)tuples, -1);
+            for (auto &kv : s.trans) {
+                long long idx = 0, stv = 1;
+                for (size_t k = 0; k < s.first_vars.size(); k++) {
+                    idx += (long long)(kv.first[k] - lb[s.first_vars[k]]) * stv;
+                    stv *= (long long)ub[s.first_vars[k]] - lb[s.first_vars[k]] + 1;
+                }
+                out.tdirect[(size_t)sd.trans_begin + (size_t)idx] = kv.second;
+            }
+        } else {
+            sd.trans_begin = (int32_t)out.trans.size();
+            sd.trans_count = (int32_t)s.trans.size();
+            for (auto &kv : s.trans) {
+                TransDesc td{(int32_t)out.transvals.size(), kv.second};
+                out.transvals.insert(out.transvals.end(), kv.first.begin(), kv.first.end());
+                out.trans.push_back(td);
+            }
         }
         sd.tag = s.tag;
         std::vector<ItemDesc> small_items, wave_items;

@@ -36,6 +36,8 @@ struct HostSet {
     bool self_loop = false;
     int32_t tag = 0;
     std::map<std::vector<int>, int> trans;  // captured first-var values -> next set index
+    bool direct = false;  // the whole space of captured value tuples has been enumerated ahead of need (pretranslate): the
+                          // device then looks the transition up in a table indexed by the tuple, not in a list
     TreeArena arena;
 };
 
@@ -64,6 +66,8 @@ struct FlatProgram {
     std::vector<SetDesc> sets;
     std::vector<ConDesc> cons;
     std::vector<int32_t> scope, code, firstvars, transvals;
+    std::vector<int32_t> fstrides;  // parallel to firstvars: mixed-radix stride of the variable in its set's direct transition table
+    std::vector<int32_t> tdirect;   // direct transition tables (SetDesc::trans_begin when trans_count < 0): next set or -1 per tuple
     std::vector<uint32_t> varcons;
     std::vector<TransDesc> trans;
     std::vector<ItemDesc> items;
@@ -86,6 +90,7 @@ public:
     bool sharded = false;    // tags are content hashes instead of ordinals
     std::vector<int> sig_vars, until_x, until_y;
     std::vector<std::unique_ptr<HostSet>> sets;
+    std::multimap<uint64_t, int> set_by_hash;  // content hash -> set index (constraintQueueEq decides; the hash only finds candidates)
     std::string error;
     std::map<std::vector<int32_t>, TableEntry> table_cache;
     bool device_tabulation = false;  // products in (kBitmapMaxBits, kBitmapMaxBitsDevice] become bitmaps filled in by the device

@@ -96,7 +96,7 @@ struct Progress {
 
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
-        arr_off, code, divmagic, words;
+        arr_off, code, divmagic, fstrides, words;
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };
 
@@ -128,6 +128,7 @@ struct Ctx {
     int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
     const int *code;
     const int *arr_data;
+    const int *tdirect;  // direct transition tables (SetDesc::trans_count < 0): one look-up per leaf, kept out of the LDS-staged image
     unsigned long long *stats;
     Progress *progress;  // null: no mirror
 };

@@ -1445,6 +1445,13 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         uint32_t fd = dom.gather(fv);  // time-0 word of that variable
         int fval = (lane < S.nfirst) ? P.v(c.o.var_lb + fv) + __ffs((int)fd) - 1 : 0;
         next_set = -1;
+        if (S.trans_count < 0) {
+            // the set's transitions are a table over the captured tuples (translated ahead of need): index = mixed radix of the
+            // captured values' bit positions
+            const int fs = lane < S.nfirst ? P.v(c.o.fstrides + S.first_off + lane) : 0;
+            const int idx = wave_sum(lane < S.nfirst ? (__ffs((int)fd) - 1) * fs : 0);
+            next_set = kload(c.tdirect, S.trans_begin + idx);
+        }
         for (int t = 0; t < S.trans_count && next_set < 0; t++) {
             const int voff = P.u(c.o.trans + (S.trans_begin + t) * 2);
             // every lane reads (no lane-predicated branch inside this loop: see STCSP_REJOIN)

@@ -30,6 +30,7 @@ constexpr unsigned long long kBudgetCodeIters = 32;      // ... and an interpret
 constexpr int kCandHdr = 8;                 // header words of a candidate record
 constexpr int kSmallMaxRows = 64;            // table rows a single lane may scan
 constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap the HOST tabulates per constraint (~0.1 us per tuple)
+constexpr long long kDirectTransMax = 1ll << 22;  // entries of one constraint set's direct transition table (4 B each)
 constexpr int kTabulateMaxStack = 32;        // operand-stack entries of k_tabulate's per-thread interpreter (deeper programs are not tabulated on the device)
 constexpr long long kBitmapMaxBitsDevice = 1ll << 28;  // ... and the largest one at all: bigger ones up to here are tabulated on the device
 
@@ -128,8 +129,8 @@ struct SetDesc {          // one constraint set (entry of Solver::seenConstraint
     int32_t self_loop;    // translation maps the set to itself whatever the leaf values
     int32_t nfirst;       // variables whose time-0 value the translation reads
     int32_t first_off;    // into firstvars[]
-    int32_t trans_begin;  // into trans[]: known (values -> next set) transitions of this set
-    int32_t trans_count;
+    int32_t trans_begin;  // into trans[]: known (values -> next set) transitions of this set; into tdirect[] when trans_count < 0
+    int32_t trans_count;  // < 0: the transitions are a table indexed by the captured tuple (fstrides[first_off + j] = stride of variable j)
     int32_t tag;          // id stored in state keys (ordinal when unsharded, content hash when sharded)
     int32_t item_begin;   // into items[]
     int32_t nitems;

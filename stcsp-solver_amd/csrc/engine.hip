@@ -110,7 +110,7 @@ struct stcsp_engine {
     int chain_small = 4, chain_big = 4, chain_thresh = 65536, chain_heavy = 400000;
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
-    DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss;
+    DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss, d_tdirect;
     DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
     bool img_in_lds = false;
     DevBuf<unsigned long long> d_slots, d_stats;
@@ -264,6 +264,7 @@ struct stcsp_engine {
         o.firstvars = put(prog.firstvars.data(), prog.firstvars.size() * 4);
         o.trans = put(prog.trans.data(), prog.trans.size() * sizeof(TransDesc));
         o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
+        o.fstrides = put(prog.fstrides.data(), prog.fstrides.size() * 4);
         o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
         {
             // x / n == mulhi(x, ceil(2^32 / n)) for n <= 32, x < 2^27 (mixed-radix tuple decomposition of the general revision)
@@ -295,6 +296,8 @@ struct stcsp_engine {
         o.words = (int)img.size();
         HIPCHK(d_img.upload(img));
         HIPCHK(d_code.upload(prog.code));
+        HIPCHK(d_tdirect.upload(prog.tdirect));  // direct transition tables: one look-up per leaf, may be MBs: not part of the image
+        ctx.tdirect = d_tdirect.p;
         // bitmaps too big for the host to tabulate: the device fills them in (k_tabulate), once -- the result goes
         // back into the SetManager's table cache, so later compiles place the finished words
         for (const TabulateTodo &td : prog.todo) {
@@ -457,10 +460,12 @@ struct stcsp_engine {
         // constraint sets whose captured `first` variables span few value tuples are translated ahead of need
         // (SURVEY 8(f) row 1): the device then never stops for them. STCSP_PRETRANSLATE=<tuples> (0 = off).
         {
-            long long tuples = 4096;
+            long long tuples = 65536;  // (~20 us of host time per tuple; the table costs 4 bytes per tuple in HBM)
+            int max_sets = 16384;      // (node records address at most 65535 sets)
             if (const char *ev = getenv("STCSP_PRETRANSLATE")) tuples = atoll(ev);
+            if (const char *ev = getenv("STCSP_PRETRANSLATE_SETS")) max_sets = std::max(1, atoi(ev));
             if (tuples > 0) {
-                const int pre = mgr.pretranslate(tuples, 256);
+                const int pre = mgr.pretranslate(tuples, max_sets);
                 if (pre < 0) return fail(pre, "%s", mgr.error.c_str());
             }
         }

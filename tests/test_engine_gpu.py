@@ -291,3 +291,46 @@ def test_device_tabulated_bitmap_equals_host_evaluation_and_oracle(stcsp, RefOra
         assert a.canonical() == ao.canonical(), f"{label}: STCSP_DEVICE_TABULATE={tab}"
         e.close()
     assert shas["1"] == shas["0"]
+
+
+# ---- constraint-set translation beyond the old 4,096-tuple cap (reference src/constraint.cpp:466-548,
+# :551-576; per-leaf use src/solveralgorithm.cpp:755-805). Three captured variables span 9 * 16 * 32 = 4,608 value tuples and
+# every tuple translates to a constraint set of its own (the reference folds `first a` to a constant, not the product around
+# it): 4,609 sets, 9,217 states, 73,728 + ... edges. The oracle (ref_dfs.cpp) re-translates at every leaf like the reference.
+MANY_SETS_BIG = """var a : [0, 8];
+var b : [0, 15];
+var c : [0, 31];
+var y : [0, 3];
+var z : [0, 1];
+y + first a * 64 + first b * 4 + first c >= 0;
+next z == z;
+next a == 0;
+next b == 0;
+next c == 0;
+"""
+
+
+def test_engine_thousands_of_constraint_sets_without_stopping(stcsp, RefOracle, monkeypatch):
+    m = stcsp.Model(text=MANY_SETS_BIG)
+    o = RefOracle(m)
+    ro = o.solve()
+    ao, _ = finish(o, ro)
+    assert ro.n_constraint_sets == 4609
+    # translated ahead of need, transitions looked up in a table indexed by the captured tuple: the device never stops
+    e = stcsp.Engine(m)
+    r = e.solve()
+    assert r.counters.translation_stops == 0
+    assert r.n_constraint_sets == 4609
+    a, _ = finish(e, r)
+    assert (a.n_live_states, a.n_live_edges) == (ao.n_live_states, ao.n_live_edges)
+    assert a.canonical_sha256() == ao.canonical_sha256()
+    assert r.counters.dominance == ro.counters.dominance
+    e.close()
+    # without the ahead-of-need translation the host is asked per batch of unknown tuples: each stop serves up to 4,096
+    # requests (many of them for the same tuple), so at most a few dozen stops for 4,608 tuples; same automaton
+    monkeypatch.setenv("STCSP_PRETRANSLATE", "0")
+    e2 = stcsp.Engine(m)
+    r2 = e2.solve()
+    assert 1 <= r2.counters.translation_stops <= 32
+    a2, _ = finish(e2, r2)
+    assert a2.canonical_sha256() == ao.canonical_sha256()
