@@ -313,6 +313,8 @@ __device__ __forceinline__ long long wave_sum64(long long v) { return (long long
 __device__ __forceinline__ void set_gate(Plan *p, unsigned launch_id, int nslots) {
     __hip_atomic_store(&p->gate, (unsigned long long)launch_id << 32 | (unsigned)nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// no round is planned: no upcoming launch may pass (the id of a launch that has already run, no slots)
+__device__ __forceinline__ void close_gate(Plan *p, unsigned next_launch) { set_gate(p, next_launch - 1u, 0); }
 // `next_launch`: id of the launch that is to execute the round planned here
 __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch) {
     const CtlLayout L(c.world);
@@ -320,7 +322,10 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch)
     uint32_t flag = 0;
     if (lane < 2) flag = ald(&c.ctl[L.misc0 + (lane == 0 ? MISC_ERROR : MISC_NMISS) * CST]);
     if (__ballot(flag != 0)) {
-        if (lane == 0) p->status = PS_HOST;
+        if (lane == 0) {
+            p->status = PS_HOST;
+            close_gate(p, next_launch);
+        }
         return;
     }
     int sp = rfl(p->sp);
@@ -337,7 +342,10 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch)
         p->arena_top = arena_top;
     }
     if (sp == 0) {
-        if (lane == 0) p->status = PS_DONE;
+        if (lane == 0) {
+            p->status = PS_DONE;
+            close_gate(p, next_launch);
+        }
         return;
     }
     const int chunk = p->chunk_r;
@@ -363,7 +371,10 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch)
         if ((unsigned long long)mc + (unsigned long long)proc * maxtake > p->cand_cap) status = PS_OUTBOX_FULL;  // a slot may meet a leaf in every expansion of its chain
     }
     if (status != PS_RUN) {
-        if (lane == 0) p->status = status;
+        if (lane == 0) {
+            p->status = status;
+            close_gate(p, next_launch);
+        }
         return;
     }
     const int parity = rfl(p->parity) ^ 1;
@@ -461,6 +472,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
             if (lane == 0) {
                 p->sp = sp;
                 p->status = PS_STACK_FULL;
+                close_gate(p, next_launch);
             }
             return;
         }
@@ -482,6 +494,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
             p->sp = sp;
             p->arena_top = arena_top;
             p->status = PS_HOST;
+            close_gate(p, next_launch);
         }
         return;
     }
@@ -496,7 +509,10 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
         p->arena_top = arena_top;
     }
     if (sp == 0) {
-        if (lane == 0) p->status = PS_DONE;
+        if (lane == 0) {
+            p->status = PS_DONE;
+            close_gate(p, next_launch);
+        }
         return;
     }
     if (!in_known) {
@@ -518,7 +534,10 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
     if (status == PS_RUN && (ns + proc * taken) * 2 > slot_cap) status = PS_NEED_TABLE;
     if (status == PS_RUN && c.sharded && (unsigned long long)wave_max(mc) + (unsigned long long)proc * maxtake > cand_cap) status = PS_OUTBOX_FULL;
     if (status != PS_RUN) {
-        if (lane == 0) p->status = status;
+        if (lane == 0) {
+            p->status = status;
+            close_gate(p, next_launch);
+        }
         return;
     }
     const int parity = parity0 ^ 1;
@@ -578,14 +597,16 @@ __global__ void k_close_segment(Ctx c) {
 #define STCSP_GEN_WAVES 4
 #endif
 template <int DR, bool L, bool CS, bool LITE>
-__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp, unsigned launch_id) {
+__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    // the planned round's gate in ONE 8-byte read (Plan::gate): is it this launch's round, and how many slots has it?
+    // the planned round's gate in ONE 8-byte read (Plan::gate): is it this launch's round, and how many slots has it? The plan
+    // pointer is a kernel argument of its own (not read through *cp), so this is the first and only load a workgroup without
+    // work waits for. A planner that stops (done, pool full, host needed) leaves the gate on the launch that has just run: the
+    // rest of the burst fails this test -- no separate look at the status word.
     static_assert(offsetof(Plan, gate) == 0, "the gate is the plan's first word");
-    const unsigned long long gate = ((const __attribute__((address_space(4))) unsigned long long *)(const __attribute__((address_space(1))) unsigned long long *)c.plan)[0];
+    const unsigned long long gate = ((const __attribute__((address_space(4))) unsigned long long *)(const __attribute__((address_space(1))) unsigned long long *)plan_arg)[0];
     if ((unsigned)(gate >> 32) != launch_id) return;  // another launch's round (this workgroup is late, or the burst ran past a stop)
-    if (kload(c.plan, (int)(offsetof(Plan, status) / 4)) != PS_RUN) return;  // the burst ran past the end
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_slots = (int)(unsigned)gate;
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
@@ -639,14 +660,14 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     }
 #endif
     if (wib == 0) {
+        // No fence on either side of the ticket: what the finalizing wavefront reads of the other workgroups are cursors and
+        // counters, all of them written by returning agent-scope atomics that completed before the workgroup's barrier
+        // above; the node and edge records themselves are only read by LATER launches (a kernel boundary away). An
+        // agent-scope fence here costs 2-3.5 us on the critical path of every round (MI355X_MICROARCH.md, fence table).
         unsigned t = 0;
-        if (lane == 0) {
-            __threadfence();
-            t = atomicAdd(&c.plan->done_blocks, 1u);
-        }
+        if (lane == 0) t = atomicAdd(&c.plan->done_blocks, 1u);
         if (rflu(t) == n_working - 1) {  // last working workgroup: every cursor of this round is final
-            if (lane == 0) c.plan->done_blocks = 0;
-            __threadfence();
+            if (lane == 0) __hip_atomic_store(&c.plan->done_blocks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t_k2 = PHASE_NOW();
             (void)t_k2;
             finalize_round(c, c.plan, lane, launch_id + 1u);

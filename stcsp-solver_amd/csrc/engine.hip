@@ -839,7 +839,7 @@ struct stcsp_engine {
         const Ctx *cp = (const Ctx *)d_ctx.p;
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
-            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, launch_seq++);
+            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
         });
     }
 
