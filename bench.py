@@ -233,17 +233,6 @@ def synthetic_workload(st, device, seconds, cpu_seconds=0.0, cpu_threads=1):
     return out
 
 
-def engine_source_sha(st):
-    """sha256 over the sources libstcsp_hip.so is built from: ties a committed PMC traffic figure to the engine it was
-    measured on (a stale profile must not decorate a changed kernel)."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(list(st.CSRC.glob("*.hip")) + list(st.CSRC.glob("dev_*.hpp")) + [st.CSRC / "device_types.hpp", st.CSRC / "cset.cpp", st.CSRC / "cset.hpp"]):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
-    return h.hexdigest()[:16]
-
-
 def make_engine_factory(st, args, local_rank):
     """The product engine -- or, for the launcher's CPU test only (--test-engine fmodel), the oracle's scalar frontier
     model over gloo: that leg exists so that the N-rank launcher path can be exercised on a box without GPUs; it is
@@ -484,7 +473,7 @@ def main():
         tf = REPO / "profiles" / "r03_p14_traffic.json"
         if args.workload == WORKLOAD and not stepped and tf.exists() and k_launches:
             tj = json.loads(tf.read_text())
-            if tj.get("engine_source_sha") == engine_source_sha(st):
+            if tj.get("engine_source_sha") == st.engine_source_sha():
                 traffic = tj["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
                 traffic_note = ("profiles/r03_p14_traffic.json (engine source sha %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                 "command, gfx950-corrected, divided by this run's launches per solve" % tj["engine_source_sha"])

@@ -115,6 +115,16 @@ class StcspError(RuntimeError):
         self.code = code
 
 
+def engine_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the sources libstcsp_hip.so is built from: ties a committed PMC figure to the
+    engine it was measured on (bench.py quotes profiles/*_traffic.json only when this matches)."""
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("dev_*.hpp")) + [CSRC / "device_types.hpp", CSRC / "cset.cpp", CSRC / "cset.hpp"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 # ------------------------------------------------------------------ library loading / building
 def build(verbose: bool = False) -> None:
     """Compile every native library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
