@@ -200,6 +200,9 @@ struct stcsp_engine {
         if (xstream2) (void)hipStreamDestroy(xstream2);
         for (int i = 0; i < 2; i++)
             if (ev_x[i]) (void)hipEventDestroy(ev_x[i]);
+        for (int i = 0; i < 2; i++)
+            if (ev_c[i]) (void)hipEventDestroy(ev_c[i]);
+        if (ev_k) (void)hipEventDestroy(ev_k);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -435,6 +438,9 @@ struct stcsp_engine {
             HIPCHK(hipStreamCreateWithPriority(&xstream2, hipStreamNonBlocking, lo));
             HIPCHK(hipEventCreateWithFlags(&ev_x[0], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&ev_x[1], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_c[0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_c[1], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_k, hipEventDisableTiming));
         }
         HIPCHK(hipHostMalloc((void **)&h_progress, sizeof(Progress)));
         memset(h_progress, 0, sizeof(Progress));
@@ -641,8 +647,14 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(&d_plan.p->edge_cap, &h_plan->edge_cap, sizeof(unsigned) * 3, hipMemcpyHostToDevice, stream));
         return STCSP_OK;
     }
+    bool tail_fresh = false;  // h_ctl / h_stats hold the state after the last device work of the search (read_plan copied them)
     int read_plan() {
         HIPCHK(hipMemcpyAsync(h_plan, d_plan.p, kPlanHeader, hipMemcpyDeviceToHost, stream));
+        // ... and, behind it, what finish() reads when this burst turns out to be the last one: the control block and the
+        // statistics (a few KB; a separate copy + synchronisation at the end costs ~40 us of every solve)
+        if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
+        HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         if (streaming && ctx.progress) {
             // instead of sleeping in the synchronisation: watch the progress mirror and ship what the launches
             // of the running burst have finished
@@ -662,6 +674,7 @@ struct stcsp_engine {
         }
         HIPCHK(hipStreamSynchronize(stream));
         levels = h_plan->rounds;
+        tail_fresh = !sharded;  // (the stepping interface enqueues commit / adopt / donate work between its reads)
         return STCSP_OK;
     }
     Progress *h_progress = nullptr;
@@ -700,6 +713,7 @@ struct stcsp_engine {
     }
     unsigned launch_seq = 0;  // id of the next k_expand launch (Plan::gate)
     int replan() {
+        tail_fresh = false;
         hipLaunchKernelGGL(k_replan, dim3(1), dim3(64), 0, stream, ctx, launch_seq);
         HIPCHK(hipGetLastError());
         return STCSP_OK;
@@ -707,6 +721,7 @@ struct stcsp_engine {
 
     int begin() {
         HIPCHK(hipSetDevice(device));
+        tail_fresh = false;
         std::fill(edge_count.begin(), edge_count.end(), 0u);
         n_states = 0;
         truncated = false;
@@ -720,6 +735,7 @@ struct stcsp_engine {
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
         if (d_sdeg.p) HIPCHK(hipMemsetAsync(d_sdeg.p, 0, d_sdeg.n * sizeof(uint32_t), stream));
         ev_x_used[0] = ev_x_used[1] = false;
+        ev_k_used = false;
         memset(h_progress, 0, sizeof(Progress));
         prog_have = false;
         prog_gen = 0;
@@ -797,6 +813,9 @@ struct stcsp_engine {
     int read_ctl() {
         HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        return parse_ctl();
+    }
+    int parse_ctl() {
         for (int r = 0; r < R; r++) edge_count[r] = h_ctl[L.edge0 + r * CST];
         n_states = h_ctl[L.misc0 + MISC_NSTATES * CST];
         uint32_t e = h_ctl[L.misc0 + MISC_ERROR * CST];
@@ -861,6 +880,7 @@ struct stcsp_engine {
         // a solve in progress (stepping interface) owns the control block and the statistics; a finished one keeps its
         // cursors (export may still follow): only the error / miss words and the work counters are reset here
         if (begun && !finished) return fail(STCSP_E_STATE, "propagate inside a solve that has not finished");
+        tail_fresh = false;
         HIPCHK(hipSetDevice(device));
         int rc = flush_ctx();
         if (rc != STCSP_OK) return rc;
@@ -899,6 +919,9 @@ struct stcsp_engine {
     // partialorder_14's 95 MB is 1.7 ms at PCIe speed: more than a third of its whole solve when done afterwards)
     hipStream_t xstream = nullptr, xstream2 = nullptr;  // chunks alternate between the two: one transposes while the other's copies are on the link
     hipEvent_t ev_x[2] = {nullptr, nullptr};            // ... recorded behind the last transposition kernel of each
+    hipEvent_t ev_c[2] = {nullptr, nullptr};            // ... and behind the D2H copies of its last chunk
+    hipEvent_t ev_k = nullptr;                          // ... and behind the last key-splitting kernel (xstream)
+    bool ev_k_used = false;
     bool ev_x_used[2] = {false, false};
     DevBuf<uint32_t> d_sdeg;                            // out-degree of every state, counted by the transposition kernels as the log streams out
     unsigned chunk_no = 0;
@@ -994,6 +1017,7 @@ struct stcsp_engine {
         HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
         HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
         HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
+        HIPCHK(hipEventRecord(ev_c[xi], xs));
         for (int r = 0; r < R; r++) streamed_r[r] = to[r];
         streamed += M;
         return STCSP_OK;
@@ -1026,6 +1050,8 @@ struct stcsp_engine {
         hipLaunchKernelGGL(k_stream_keys, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, xstream, (const uint32_t *)d_state_keys.p, ctx.KL,
                            ctx.sig_len, streamed_states, upto, h_cid, h_sig);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev_k, xstream));
+        ev_k_used = true;
         streamed_states = upto;
         return STCSP_OK;
     }
@@ -1071,6 +1097,7 @@ struct stcsp_engine {
                 }
                 HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
             }
+            tail_fresh = false;
             for (int k = 0; k < burst; k++) {
                 switch (DR) {
                     case 1: launch_expand<1>(); break;
@@ -1263,10 +1290,16 @@ struct stcsp_engine {
         dbg_nodes.clear();
         dbg_open.clear();
         ev_used = 0;
-        // the control block and the statistics in one go (each synchronous small copy costs ~100 us of host time)
-        if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
-        HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        int rc = read_ctl();
+        // the control block and the statistics: already here when the last burst's read_plan brought them and nothing has run
+        // since; else in one go (each synchronous small copy costs ~100 us of host time)
+        int rc;
+        if (tail_fresh) {
+            rc = parse_ctl();
+        } else {
+            if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
+            HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            rc = read_ctl();
+        }
         if (rc != STCSP_OK) return rc;
         stats_fresh = true;
         return read_counters(snap);
@@ -1323,6 +1356,7 @@ struct stcsp_engine {
     }
     int commit(const void *records, int64_t count) {
         if (!begun) return fail(STCSP_E_STATE, "commit before begin");
+        tail_fresh = false;
         // the outbox has been handed over: empty it
         packed = false;
         HIPCHK(hipMemsetAsync(d_ctl.p + L.cand0, 0, (size_t)(L.edge0 - L.cand0) * sizeof(uint32_t), stream));
@@ -1375,6 +1409,7 @@ struct stcsp_engine {
     // ---- frontier redistribution (stcsp_engine.h): the oldest open nodes leave / received ones join
     int donate(int64_t want, void **ptr, int64_t *count) {
         if (!begun || !sharded) return fail(STCSP_E_STATE, "donate is part of the sharded stepping interface (after begin)");
+        tail_fresh = false;
         *ptr = nullptr;
         *count = 0;
         if (want <= 0) return STCSP_OK;
@@ -1422,6 +1457,7 @@ struct stcsp_engine {
     }
     int adopt(const void *records, int64_t count) {
         if (!begun || !sharded) return fail(STCSP_E_STATE, "adopt is part of the sharded stepping interface (after begin)");
+        tail_fresh = false;
         if (count <= 0) return STCSP_OK;
         int rc = STCSP_OK;
         if (!host_view_fresh && ((rc = read_ctl()) || (rc = read_plan()))) return rc;  // (waits for a commit in flight)
@@ -1611,12 +1647,18 @@ struct stcsp_engine {
             // the whole log went through the transposition kernels, which counted the out-degrees on their way: the first
             // round of the ok-fixpoint is one pass over the states. Nobody without an out-edge (every shipped example):
             // every logged edge is kept and the streamed arrays are the result.
+            // ONE synchronisation for everything that is still in flight: the main stream waits for the export streams' last
+            // chunks (transposition kernels AND their copies) and the key arrays, marks, copies the verdict and the flags
             for (int i = 0; i < 2; i++)
-                if (ev_x_used[i]) HIPCHK(hipStreamWaitEvent(stream, ev_x[i], 0));
+                if (ev_x_used[i]) HIPCHK(hipStreamWaitEvent(stream, ev_c[i], 0));
+            if (ev_k_used) HIPCHK(hipStreamWaitEvent(stream, ev_k, 0));
             hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_sdeg.p, d_fail.p, d_post.p);
-            uint32_t changed = 0;
-            HIPCHK(hipMemcpyAsync(&changed, d_post.p, sizeof changed, hipMemcpyDeviceToHost, stream));
+            uint32_t changed_local = 0;
+            uint32_t *changed_p = h_begin ? h_begin : &changed_local;  // (pinned scratch of begin(): idle by now)
+            HIPCHK(hipMemcpyAsync(changed_p, d_post.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
+            const uint32_t changed = *changed_p;
             quick_final = !changed;
             if (!quick_final) {  // somebody failed: the full fixpoint below starts from scratch
                 HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
@@ -1665,8 +1707,10 @@ struct stcsp_engine {
             HIPCHK(hipMemsetAsync(d_outdeg.p, 0, (size_t)n_states * sizeof(uint32_t), stream));
             hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_outdeg.p, d_fail.p, d_post.p);
         }
-        HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        if (!quick_final) {  // (the quick path brought the flags with its one synchronisation)
+            HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
         lap("D2H result arrays");
         { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }  // cid / sig arrays complete
         int64_t ok_states = 0;
