@@ -94,7 +94,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
 #ifdef STCSP_PHASES
     // (hipcc 7.2 fails on this one instantiation of the instrumented build -- "Illegal instruction detected:
     // V_CMP_NE_U32_e32 0, $src_shared_base" -- with the stack in it; the product build is not affected)
-    const bool use_sib = chain > 2 && !(DR == 4 && L && CS && !LITE);
+    const bool use_sib = chain > 2 && !(DR == 4 && L && !LITE);  // (round 3: <4,true,false,false> fails the same way)
 #else
     const bool use_sib = chain > 2;
 #endif
