@@ -5,7 +5,9 @@ from collections import defaultdict
 d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else "k_expand"
 out = {}
-for f in sorted(glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)):
+import os
+files = sorted(glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
+for f in files[-1:]:  # the newest run only (gpurun merges every call's output into the same local directory)
     sums, disp = defaultdict(float), defaultdict(set)
     for row in csv.DictReader(open(f)):
         if sub in row["Kernel_Name"]:
