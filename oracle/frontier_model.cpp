@@ -626,4 +626,24 @@ int stcsp_fmodel_propagate(stcsp_fmodel *h, int set, uint32_t expire, uint32_t *
     return h->m.propagate(set, expire, block) ? 1 : 0;
 }
 
+// Test hook for the product's ahead-of-need translation (cset.cpp SetManager::pretranslate, compiled into this library):
+// runs it on this model's set registry and compiles the flat program; reports the sets known afterwards, how many of them
+// have a direct (tuple-indexed) transition table and the size of all those tables. Returns the number of transitions added.
+int stcsp_fmodel_pretranslate(stcsp_fmodel *h, long long max_tuples, int max_sets, int *n_sets, int *n_direct, long long *table_entries) {
+    const int added = h->m.mgr.pretranslate(max_tuples, max_sets);
+    if (added < 0) {
+        h->m.err = h->m.mgr.error;
+        return added;
+    }
+    const int rc = h->m.recompile();  // (the model interprets the flat program: it must know the new sets)
+    if (rc != STCSP_OK) return rc;
+    const stcsp::FlatProgram &prog = h->m.prog;
+    int direct = 0;
+    for (const stcsp::SetDesc &sd : prog.sets) direct += sd.trans_count < 0;
+    if (n_sets) *n_sets = (int)h->m.mgr.sets.size();
+    if (n_direct) *n_direct = direct;
+    if (table_entries) *table_entries = (long long)prog.tdirect.size();
+    return added;
+}
+
 }  // extern "C"

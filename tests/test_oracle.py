@@ -156,3 +156,35 @@ def test_parallel_restatement_matches_reference_golden(stcsp, oracle_lib, RefOra
         assert r.counters.dominance == g["dom"]
         if g["fail"] == 0:
             assert r.n_states == g["node"] and r.counters.search_nodes == g["search"]
+
+
+# ---- the product's ahead-of-need constraint-set translation (cset.cpp SetManager::pretranslate, linked into the oracle
+# library with the frontier model) on the CPU: what gets translated, which sets get a tuple-indexed transition table, and
+# that a model solved AFTER it gives the reference's automaton and set count
+PRETRANSLATE_CASES = [
+    # (model, sets after pretranslation, sets with a direct table, direct-table entries)
+    ("name:partialorder_10", 2, 1, 10 * 2 ** 10 * 2),   # 20,480 captured tuples, cut to 2 by the unary `first` constraints
+    ("name:partialorder_14", 2, 1, 14 * 2 ** 14 * 2),   # 458,752 -> 2
+    ("var x:[0,31]; var y:[0,31]; var z:[0,1]; y + z == first x; next z == 1 - z;", 33, 1, 32),
+    ("var x:[0,20]; var w:[0,3]; var y:[0,24]; var z:[0,1]; y == first x + first w + z; next z == 1 - z; first w <= 1;", 43, 1, 84),
+]
+
+
+@pytest.mark.parametrize("spec,n_sets,n_direct,entries", PRETRANSLATE_CASES)
+def test_pretranslation_on_the_cpu(stcsp, oracle_lib, RefOracle, FrontierModel, spec, n_sets, n_direct, entries):
+    import ctypes as C
+    oracle_lib.stcsp_fmodel_pretranslate.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    m = stcsp.Model.from_name(spec[5:]) if spec.startswith("name:") else stcsp.Model(text=spec)
+    f = FrontierModel(m)
+    ns, nd, te = C.c_int(), C.c_int(), C.c_longlong()
+    added = oracle_lib.stcsp_fmodel_pretranslate(f._h, 65536, 16384, C.byref(ns), C.byref(nd), C.byref(te))
+    assert added >= 1
+    assert (ns.value, nd.value, te.value) == (n_sets, n_direct, entries)
+    if not spec.startswith("name:partialorder_14"):  # (the scalar model needs minutes for partialorder_14)
+        r = f.solve()
+        a = f.automaton(r).traverse().renumber()
+        o = RefOracle(m)
+        ro = o.solve()
+        ao = o.automaton(ro).traverse().renumber()
+        assert a.canonical_sha256() == ao.canonical_sha256()
+        assert r.n_constraint_sets == ro.n_constraint_sets
