@@ -717,10 +717,12 @@ int SetManager::compile(FlatProgram &out) {
                 st *= ub[v] - lb[v] + 1;
             }
         }
-        if (s.direct) {
+        long long direct_tuples = 1;
+        for (int v : s.first_vars) direct_tuples = std::min<long long>(direct_tuples * ((long long)ub[v] - lb[v] + 1), kDirectTransMax + 1);
+        // (all the tables of a program together stay below kDirectTransTotalMax entries: the sets beyond that keep their lists)
+        if (s.direct && direct_tuples <= kDirectTransMax && (long long)out.tdirect.size() + direct_tuples <= kDirectTransTotalMax) {
             // transition table indexed by the captured tuple (-1: no leaf can have it, or not translated yet -> the host is asked)
-            long long tuples = 1;
-            for (int v : s.first_vars) tuples *= (long long)ub[v] - lb[v] + 1;
+            const long long tuples = direct_tuples;
             sd.trans_begin = (int32_t)out.tdirect.size();
             sd.trans_count = -1;
             out.tdirect.resize(out.tdirect.size() + (size_t)tuples, -1);
