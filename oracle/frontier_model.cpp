@@ -646,4 +646,18 @@ int stcsp_fmodel_pretranslate(stcsp_fmodel *h, long long max_tuples, int max_set
     return added;
 }
 
+// Test / sizing hook: byte sizes of the flat program's sections [sets, sweep records, itemrows, wavefront item records, scope,
+// strides, code, cons, tables, transition lists + values, direct transition tables], as the engine would lay them out.
+int stcsp_fmodel_program_sizes(stcsp_fmodel *h, long long *out, int n) {
+    const stcsp::FlatProgram &g = h->m.prog;
+    long long witems = 0;
+    for (const stcsp::SetDesc &sd : g.sets) witems += sd.nitems - sd.nsmall;
+    const long long v[11] = {(long long)(g.sets.size() * sizeof(stcsp::SetDesc)), (long long)(g.items.size() * 16), (long long)(g.itemrows.size() * 4),
+                             witems * (long long)sizeof(stcsp::ItemDesc), (long long)(g.scope.size() * 4), (long long)(g.strides.size() * 4),
+                             (long long)(g.code.size() * 4), (long long)(g.cons.size() * sizeof(stcsp::ConDesc)), (long long)(g.tables.size() * 4),
+                             (long long)(g.trans.size() * sizeof(stcsp::TransDesc) + g.transvals.size() * 4), (long long)(g.tdirect.size() * 4)};
+    for (int i = 0; i < n && i < 11; i++) out[i] = v[i];
+    return 11;
+}
+
 }  // extern "C"

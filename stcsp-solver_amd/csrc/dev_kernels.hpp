@@ -188,7 +188,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
             Dom<DR> child = dom;
             child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: waits on the sibling stack, or goes to the frontier
             dom.set(bo.bvar, bo.D & bo.lowmask, lane);     // lower half: next in the chain, or stored too
-            if (use_sib && !last && sd < kSibDepth) {
+            if (use_sib && !last && sd < c.sib_depth) {
                 const int sb = sib_off + sd * c.NS;
                 if (lane < 4) stcsp_lds[sb + lane] = (int)(lane == 0 ? hd.h0 : (lane == 1 ? hd.h1 : (lane == 2 ? cw2 : hd.expire)));
 #pragma unroll
@@ -596,8 +596,17 @@ __global__ void k_close_segment(Ctx c) {
 #ifndef STCSP_GEN_WAVES
 #define STCSP_GEN_WAVES 4
 #endif
-template <int DR, bool L, bool CS, bool LITE>
-__global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : 3)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id) {
+#ifndef STCSP_WIDE_WAVES
+#define STCSP_WIDE_WAVES 4
+#endif
+// BIG: one workgroup of 1024 threads (16 wavefronts = 4 per SIMD) per CU shares ONE staged copy of the program -- for LITE
+// programs whose tables do not fit beside four 256-thread workgroups' copies (the synthetic 64 x 32 family: 122 KB of sweep
+// records, dirty rows and tables). Same code; the workgroup size is read from blockDim.
+#ifndef STCSP_BIG_WAVES
+#define STCSP_BIG_WAVES 16  // wavefronts of a big workgroup
+#endif
+template <int DR, bool L, bool CS, bool LITE, bool BIG = false>
+__global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : STCSP_WIDE_WAVES)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     // the planned round's gate in ONE 8-byte read (Plan::gate): is it this launch's round, and how many slots has it? The plan
@@ -609,19 +618,20 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
     if ((unsigned)(gate >> 32) != launch_id) return;  // another launch's round (this workgroup is late, or the burst ran past a stop)
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_slots = (int)(unsigned)gate;
+    const int wpb = BIG ? STCSP_BIG_WAVES : 4;  // wavefronts per workgroup
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
-    if ((int)blockIdx.x * 4 >= n_slots) return;
-    const unsigned n_working = (unsigned)min((n_slots + 3) / 4, (int)gridDim.x);
+    if ((int)blockIdx.x * wpb >= n_slots) return;
+    const unsigned n_working = (unsigned)min((n_slots + wpb - 1) / wpb, (int)gridDim.x);
     const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
     const unsigned long long t_k0 = PHASE_NOW();
     (void)t_k0;
     if (img_words) {
         const uint4 *src = (const uint4 *)c.img;
         uint4 *dst = (uint4 *)smem;
-        for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
+        for (int k = threadIdx.x; k < img_words / 4; k += (BIG ? STCSP_BIG_WAVES * 64 : 256)) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE);
+    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE, c.sib_depth);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront, then its counters
@@ -642,15 +652,15 @@ __global__ __launch_bounds__(256, (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES :
         a.cand_cap = pl(offsetof(Plan, cand_cap));
         a.parity = (int)pl(offsetof(Plan, parity));
     }
-    const int total_waves = gridDim.x * 4;
+    const int total_waves = gridDim.x * wpb;
     const unsigned long long t_k1 = PHASE_NOW();
     (void)t_k1;
     WaveEnv<DR> env;
     uint32_t hot[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
-    for (int gw = blockIdx.x * 4 + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
-    flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
+    for (int gw = blockIdx.x * wpb + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+    flush_env<DR>(c, env, blockIdx.x * wpb + wib, lane);
     __syncthreads();
 #ifdef STCSP_PHASES
     if (threadIdx.x == 0) {
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         for (int k = threadIdx.x; k < img_words / 4; k += 256) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE);
+    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE, c.sib_depth);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
     int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;

@@ -25,12 +25,12 @@ constexpr int kLdsStatWords = 12;
 // LDS words of one wavefront: [lane-enumerated values | expression stack] (general revisions only) + the
 // AND-accumulator copy of the block + the counters. LITE kernels (no general revision) keep the last part only.
 // ... + the sibling stack of the chained expansions (dev_kernels.hpp expand_node): kSibDepth node records.
-constexpr int kSibDepth = 4;
+constexpr int kSibDepth = 4;  // (default; Ctx::sib_depth is what a launch uses: the big-workgroup variant trades depth for LDS)
 __host__ __device__ inline int wave_sib_offset(int NK, int stack_slots, bool lite) {
     return (lite ? 0 : (kMaxLowVars + stack_slots) * 64) + ((NK + kLdsStatWords + 63) & ~63);
 }
-__host__ __device__ inline int wave_scratch_words(int NK, int stack_slots, bool lite) {
-    return wave_sib_offset(NK, stack_slots, lite) + kSibDepth * ((4 + NK + 3) & ~3);
+__host__ __device__ inline int wave_scratch_words(int NK, int stack_slots, bool lite, int sib_depth) {
+    return wave_sib_offset(NK, stack_slots, lite) + sib_depth * ((4 + NK + 3) & ~3);
 }
 constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
@@ -126,6 +126,8 @@ struct Ctx {
     int max_iw;  // widest dirty mask (words) over the program's constraint sets
     // ---- beyond word 63: general wavefront revisions and diagnostics only
     int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
+    int sib_depth;                   // node records on a wavefront's sibling stack (kSibDepth; 2 under the big-workgroup variant)
+    int pad1;
     const int *code;
     const int *arr_data;
     const int *tdirect;  // direct transition tables (SetDesc::trans_count < 0): one look-up per leaf, kept out of the LDS-staged image

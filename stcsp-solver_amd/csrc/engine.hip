@@ -123,6 +123,7 @@ struct stcsp_engine {
     std::vector<long long> dbg_open;
     bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true, ..>
     bool lite = false;            // no constraint needs the general wavefront revision: k_expand<.., .., .., true>
+    bool big = false;             // 1024-thread workgroups around one LDS copy of a LITE program: k_expand<.., true, .., true, true>
     bool interpreted = false;     // some wavefront-revised constraint has no tuple bitmap (postfix interpreter: uniformly expensive nodes)
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
@@ -226,9 +227,23 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
         // node header word 2 = set ordinal (16 bits) | dirty seed << 16
         if (prog.sets.size() > 0xffffu) return fail(STCSP_E_UNSUPPORTED, "%zu constraint sets; node records address at most 65535", prog.sets.size());
+        // LITE: every wavefront-revised constraint is a tuple bitmap with at most one violating tuple. Its
+        // revision then either cannot prune (two or more open variables: the product of the others exceeds the
+        // forbidden set) or is the one-open-variable look-up, so the general enumeration (tuple lanes, odometer,
+        // bytecode interpreter, their LDS scratch and ~25 VGPRs) is compiled out: more resident wavefronts.
+        lite = true;
+        interpreted = false;
+        for (const SetDesc &sd : prog.sets)
+            for (int i = sd.nsmall; i < sd.nitems; i++) {
+                const ConDesc &cd = prog.cons[prog.items[sd.item_begin + i].con];
+                lite = lite && cd.bitmap_off >= 0 && cd.n_forbidden >= 0 && cd.n_forbidden <= 1;
+                interpreted = interpreted || cd.bitmap_off < 0;
+            }
+        if (const char *ev = getenv("STCSP_LITE")) lite = lite && atoi(ev) != 0;  // tuning switch
         // one contiguous image; every section starts on a 16-byte boundary
         std::vector<uint32_t> img;
         ImgOff o{};
+        int tables_end = 0;
         auto put = [&](const void *data, size_t bytes) {
             while (img.size() & 3) img.push_back(0u);
             int off = (int)img.size();
@@ -291,10 +306,21 @@ struct stcsp_engine {
         o.scope = put(prog.scope.data(), prog.scope.size() * 4);
         o.strides = put(prog.strides.data(), prog.strides.size() * 4);
         cut();
-        o.code = put(prog.code.data(), prog.code.size() * 4);
-        cut();
-        o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
-        o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
+        if (lite) {
+            // a LITE kernel never reads the bytecode: the tables come first, so that "everything the kernel reads" is a
+            // prefix of the image (tables_end) -- what the big-workgroup variant stages
+            o.tables = put(prog.tables.data(), prog.tables.size() * 4);
+            while (img.size() & 3) img.push_back(0u);
+            tables_end = (int)img.size();
+            o.code = put(prog.code.data(), prog.code.size() * 4);
+            o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
+        } else {
+            o.code = put(prog.code.data(), prog.code.size() * 4);
+            cut();
+            o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
+            o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
+            tables_end = 0;
+        }
         while (img.size() & 3) img.push_back(0u);
         o.words = (int)img.size();
         HIPCHK(d_img.upload(img));
@@ -333,33 +359,41 @@ struct stcsp_engine {
         compact_sweeps = false;
         for (const SetDesc &sd : prog.sets) compact_sweeps = compact_sweeps || sd.nsmall > kCompactSweepItems;
         ctx.stack_slots = prog.max_stack + 2;
-        // LITE: every wavefront-revised constraint is a tuple bitmap with at most one violating tuple. Its
-        // revision then either cannot prune (two or more open variables: the product of the others exceeds the
-        // forbidden set) or is the one-open-variable look-up, so the general enumeration (tuple lanes, odometer,
-        // bytecode interpreter, their LDS scratch and ~25 VGPRs) is compiled out: more resident wavefronts.
-        lite = true;
-        interpreted = false;
-        for (const SetDesc &sd : prog.sets)
-            for (int i = sd.nsmall; i < sd.nitems; i++) {
-                const ConDesc &cd = prog.cons[prog.items[sd.item_begin + i].con];
-                lite = lite && cd.bitmap_off >= 0 && cd.n_forbidden >= 0 && cd.n_forbidden <= 1;
-                interpreted = interpreted || cd.bitmap_off < 0;
-            }
-        if (const char *ev = getenv("STCSP_LITE")) lite = lite && atoi(ev) != 0;  // tuning switch
         ctx.max_iw = 1;
         int max_nfirst = 0;
         for (const SetDesc &sd : prog.sets) {
             ctx.max_iw = std::max(ctx.max_iw, sd.iw);
             max_nfirst = std::max(max_nfirst, sd.nfirst);
         }
-        const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite) * sizeof(int);
+        ctx.sib_depth = kSibDepth;
+        const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite, ctx.sib_depth) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
         img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
         if (const char *ev = getenv("STCSP_IMG_LDS")) img_in_lds = img_in_lds && atoi(ev) != 0;  // tuning switch
         ctx.stage_words = img_in_lds ? o.words : 0;
         lds_bytes = scratch + (size_t)ctx.stage_words * 4;
-        const bool try_prefix = !img_in_lds && !(getenv("STCSP_IMG_LDS") && atoi(getenv("STCSP_IMG_LDS")) == 0);
+        // Big workgroups: a LITE program too big for four copies per CU but not for one (<= 160 KB with the scratch of 16
+        // wavefronts at sibling depth 2) runs as ONE 1024-thread workgroup per CU around one staged copy -- the same 4
+        // wavefronts per SIMD as four 256-thread workgroups, every program read out of LDS instead of L2.
+        big = false;
+        if (lite && !img_in_lds && tables_end > 0) {
+            int depth = kSibDepth;
+            if (const char *ev = getenv("STCSP_BIG_DEPTH")) depth = std::max(1, std::min(kSibDepth, atoi(ev)));
+            size_t scratch_big = 0;
+            for (;; depth--) {  // the deepest sibling stack that still fits
+                scratch_big = (size_t)STCSP_BIG_WAVES * wave_scratch_words(ctx.NK, ctx.stack_slots, true, depth) * sizeof(int);
+                if ((size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024 || depth == 2) break;
+            }
+            big = (size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024;
+            if (const char *ev = getenv("STCSP_BIG")) big = big && atoi(ev) != 0;  // tuning switch
+            if (big) {
+                ctx.sib_depth = depth;
+                ctx.stage_words = tables_end;
+                lds_bytes = (size_t)tables_end * 4 + scratch_big;
+            }
+        }
+        const bool try_prefix = !big && !img_in_lds && !(getenv("STCSP_IMG_LDS") && atoi(getenv("STCSP_IMG_LDS")) == 0);
         // Grid = exactly the workgroups that are resident at once: wavefronts take node slots with
         // a static grid stride, so a workgroup that has to wait for a free CU slot would start its
         // share only when another one has finished all of its own (a 2x tail).
@@ -372,7 +406,19 @@ struct stcsp_engine {
                 case 2: fn = expand_fn<2>(); break;
                 default: fn = expand_fn<4>(); break;
             }
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes);
+            if (big) {
+                // more than 64 KB of dynamic LDS has to be asked for, per kernel (the probe kernel stages the same image)
+                const void *pf;
+                switch (DR) {
+                    case 1: pf = probe_fn<1>(); break;
+                    case 2: pf = probe_fn<2>(); break;
+                    default: pf = probe_fn<4>(); break;
+                }
+                HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                HIPCHK(hipFuncSetAttribute(pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            }
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, big ? STCSP_BIG_WAVES * 64 : 256, lds_bytes);
+            if (big && (e != hipSuccess || per_cu < 1)) return fail(STCSP_E_INTERNAL, "big-workgroup kernel does not fit a CU (%zu B of LDS)", lds_bytes);
             if (try_prefix && e == hipSuccess && per_cu > 0) {
                 // the longest prefix of whole hot sections that costs no resident workgroup: the kernel's
                 // registers allow per_cu workgroups, each may use 160 KB / per_cu of LDS (<= 64 KB)
@@ -399,7 +445,7 @@ struct stcsp_engine {
             }
             if (getenv("STCSP_DEBUG"))
                 fprintf(stderr, "[engine] %s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
-                        lite ? "LITE" : "general", o.words, img_in_lds ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
+                        big ? "LITE big-workgroup" : lite ? "LITE" : "general", o.words, img_in_lds || big ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
         }
         return STCSP_OK;
     }
@@ -832,7 +878,7 @@ struct stcsp_engine {
     // items: CS), no general wavefront revision (LITE)
     template <int DRT, typename F>
     void with_variant(F &&f) const {
-        const int v = (img_in_lds ? 4 : 0) | (compact_sweeps ? 2 : 0) | (lite ? 1 : 0);
+        const int v = (img_in_lds || big ? 4 : 0) | (compact_sweeps ? 2 : 0) | (lite ? 1 : 0);
         switch (v) {
             case 0: f(std::integral_constant<int, 0>{}); break;
             case 1: f(std::integral_constant<int, 1>{}); break;
@@ -850,6 +896,17 @@ struct stcsp_engine {
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
             fn = (const void *)k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
+            if constexpr ((V & 5) == 5)
+                if (big) fn = (const void *)k_expand<DRT, true, (V & 2) != 0, true, true>;
+        });
+        return fn;
+    }
+    template <int DRT>
+    const void *probe_fn() const {
+        const void *fn = nullptr;
+        with_variant<DRT>([&](auto v) {
+            constexpr int V = decltype(v)::value;
+            fn = (const void *)k_probe<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
         });
         return fn;
     }
@@ -858,6 +915,11 @@ struct stcsp_engine {
         const Ctx *cp = (const Ctx *)d_ctx.p;
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
+            if constexpr ((V & 5) == 5)
+                if (big) {
+                    hipLaunchKernelGGL((k_expand<DRT, true, (V & 2) != 0, true, true>), dim3(max_blocks), dim3(STCSP_BIG_WAVES * 64), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+                    return;
+                }
             hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
         });
     }
