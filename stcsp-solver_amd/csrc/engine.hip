@@ -377,7 +377,8 @@ struct stcsp_engine {
         // wavefronts at sibling depth 2) runs as ONE 1024-thread workgroup per CU around one staged copy -- the same 4
         // wavefronts per SIMD as four 256-thread workgroups, every program read out of LDS instead of L2.
         big = false;
-        if (lite && !img_in_lds && tables_end > 0) {
+        const char *big_env = getenv("STCSP_BIG");  // 0: never; 2: whenever it fits (tests: small programs through the big-workgroup kernel)
+        if (lite && tables_end > 0 && (!img_in_lds || (big_env && atoi(big_env) == 2))) {
             int depth = kSibDepth;
             if (const char *ev = getenv("STCSP_BIG_DEPTH")) depth = std::max(1, std::min(kSibDepth, atoi(ev)));
             size_t scratch_big = 0;
@@ -386,8 +387,9 @@ struct stcsp_engine {
                 if ((size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024 || depth == 2) break;
             }
             big = (size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024;
-            if (const char *ev = getenv("STCSP_BIG")) big = big && atoi(ev) != 0;  // tuning switch
+            if (big_env) big = big && atoi(big_env) != 0;
             if (big) {
+                img_in_lds = false;
                 ctx.sib_depth = depth;
                 ctx.stage_words = tables_end;
                 lds_bytes = (size_t)tables_end * 4 + scratch_big;

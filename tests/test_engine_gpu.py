@@ -129,6 +129,38 @@ def test_engine_synthetic_parity(stcsp, RefOracle, shape):
     assert r.counters.fails > 0 or shape[0] == 8
 
 
+@pytest.mark.parametrize("name,shape", [("partialorder_10", None), ("partialorder_13", None), ("partialorder_14", None),
+                                        ("synth95", (16, 8, 95, 4, 3)), ("synth88", (16, 8, 88, 4, 4)), ("synth125", (24, 8, 125, 4, 7))])
+def test_engine_big_workgroup_kernel_parity(stcsp, RefOracle, golden, monkeypatch, capfd, name, shape):
+    """The big-workgroup variant of k_expand (one 1024-thread workgroup per CU around ONE LDS copy of a LITE program: what the
+    synthetic 64 x 32 family and partialorder_18 run under) forced onto programs small enough for the CPU oracle
+    (STCSP_BIG=2): same automaton as oracle/ref_dfs.cpp / the recorded reference values, same search tree as the regular
+    kernel."""
+    m = stcsp.Model(text=stcsp.instances.synthetic(*shape)) if shape else stcsp.Model.from_name(name)
+    monkeypatch.setenv("STCSP_BIG", "0")
+    e0 = stcsp.Engine(m)
+    r0 = e0.solve()
+    a0, _ = finish(e0, r0)
+    monkeypatch.setenv("STCSP_BIG", "2")
+    monkeypatch.setenv("STCSP_DEBUG", "1")
+    capfd.readouterr()
+    e = stcsp.Engine(m)
+    r = e.solve()
+    assert "big-workgroup kernel" in capfd.readouterr().err
+    monkeypatch.delenv("STCSP_DEBUG")
+    a, _ = finish(e, r)
+    if shape:
+        o = RefOracle(m)
+        ao, _ = finish(o, o.solve())
+        assert a.canonical() == ao.canonical()
+        assert r.counters.fails > 0
+    else:
+        assert a.canonical_sha256() == golden[name]["canonical_sha256"]
+    assert a.canonical_sha256() == a0.canonical_sha256()
+    assert (r.counters.search_nodes, r.counters.fails, r.counters.leaves, r.n_states) == \
+           (r0.counters.search_nodes, r0.counters.fails, r0.counters.leaves, r0.n_states)
+
+
 def test_engine_synthetic_64x32_timebox(stcsp):
     """64 vars x |D| = 32, 602 point + 6 stream constraints: a time-boxed throughput run (no
     implementation reaches a leaf quickly). Exercises 4-register blocks, the global-memory

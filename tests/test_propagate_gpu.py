@@ -108,6 +108,30 @@ def test_node_propagation_equals_gac_fixpoint(stcsp, oracle_lib, FrontierModel, 
     assert n_fail < count  # the sample must exercise surviving blocks too
 
 
+@pytest.mark.parametrize("name,shape,force", [("synth64x32", (64, 32, 602, 6, 20261003), False), ("partialorder_14", None, True),
+                                              ("synth95", (16, 8, 95, 4, 20261003), True)])
+def test_node_propagation_under_the_big_workgroup_layout(stcsp, oracle_lib, FrontierModel, monkeypatch, capfd, name, shape, force):
+    """The node-level seam where the program is staged for the big-workgroup kernel (tables in LDS, bytecode not staged):
+    the 64 x 32 instance takes that layout by itself, smaller programs are forced onto it. Blocks and verdicts = the scalar
+    GAC model's."""
+    m = stcsp.Model(text=inst.synthetic(*shape)) if shape else stcsp.Model.from_name(name)
+    rng = np.random.default_rng(20261005)
+    blocks = random_blocks(m, 2, rng, 128)
+    if force:
+        monkeypatch.setenv("STCSP_BIG", "2")
+    monkeypatch.setenv("STCSP_DEBUG", "1")
+    capfd.readouterr()
+    e = stcsp.Engine(m)
+    got, outcome, skipped = e.propagate(blocks, 0, 0)
+    assert "big-workgroup kernel" in capfd.readouterr().err
+    want, ok = fmodel_propagate(oracle_lib, FrontierModel, m, blocks)
+    assert skipped == 0
+    assert ((outcome != 0) == (ok != 0)).all()
+    live = ok != 0
+    assert (got[live] == want[live]).all()
+    assert 0 < int(live.sum())
+
+
 @pytest.mark.parametrize("shape", SYNTH_SHAPES + [(24, 8, 125, 4, 7), (20, 8, 105, 4, 3)])
 def test_engine_search_tree_equals_frontier_model(stcsp, FrontierModel, RefOracle, shape):
     """Same propagation strength => same search tree: search_nodes, fails, leaves and table size of the
