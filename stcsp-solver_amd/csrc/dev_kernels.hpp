@@ -659,7 +659,25 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     uint32_t hot[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
+#ifdef STCSP_STATIC_SLOTS
     for (int gw = blockIdx.x * wpb + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+#else
+    // Slots: the first one by position, every further one by ticket -- slots differ widely in cost (a chain of up to `chain`
+    // expansions, each anything between a failed sweep and a leaf with a new state), and with a fixed stride the round waits for
+    // the wavefront whose share happened to be the dearest. The ticket for the NEXT slot is requested before the current one is
+    // expanded (its latency disappears behind the node load); kSlotCursors counters deal interleaved tickets.
+    {
+        const CtlLayout L_(c.world);
+        const int cur = (int)(blockIdx.x % kSlotCursors);
+        uint32_t *cursor = c.ctl + L_.slotcur0 + cur * CST;
+        for (int gw = blockIdx.x * wpb + wib; gw < n_slots;) {
+            unsigned ticket = 0;
+            if (lane == 0) ticket = atomicAdd(cursor, 1u);
+            expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+            gw = total_waves + (int)rflu(ticket) * kSlotCursors + cur;
+        }
+    }
+#endif
     flush_env<DR>(c, env, blockIdx.x * wpb + wib, lane);
     __syncthreads();
 #ifdef STCSP_PHASES
@@ -678,6 +696,10 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
         if (lane == 0) t = atomicAdd(&c.plan->done_blocks, 1u);
         if (rflu(t) == n_working - 1) {  // last working workgroup: every cursor of this round is final
             if (lane == 0) __hip_atomic_store(&c.plan->done_blocks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef STCSP_STATIC_SLOTS
+            // (every other wavefront of the launch has drawn its last ticket: the counters start the next round at zero)
+            if (lane < kSlotCursors) __hip_atomic_store(&c.ctl[CtlLayout(c.world).slotcur0 + lane * CST], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             const unsigned long long t_k2 = PHASE_NOW();
             (void)t_k2;
             finalize_round(c, c.plan, lane, launch_id + 1u);

@@ -36,14 +36,16 @@ constexpr int kMissStride = 66;  // set, nfirst, 64 values
 constexpr uint32_t kPending = 0xffffffffu;
 
 // control block (u32 words; every cursor on its own 64-byte line)
+constexpr int kSlotCursors = 16;  // slot tickets of a round are dealt by this many counters (one address would serialise ~200 atomics per us)
 struct CtlLayout {
-    int out0, cand0, edge0, misc0, words;  // out0: TWO sets of R cursors (round parity)
+    int out0, cand0, edge0, misc0, slotcur0, words;  // out0: TWO sets of R cursors (round parity)
     __host__ __device__ CtlLayout(int world) {
         out0 = 0;
         cand0 = 2 * R * CST;
         edge0 = cand0 + world * R * CST;
         misc0 = edge0 + R * CST;
-        words = misc0 + 8 * CST;
+        slotcur0 = misc0 + 8 * CST;
+        words = slotcur0 + kSlotCursors * CST;
     }
     __host__ __device__ int out(int parity, int r) const { return out0 + (parity * R + r) * CST; }
 };
