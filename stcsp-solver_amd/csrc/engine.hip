@@ -535,7 +535,9 @@ struct stcsp_engine {
         // frontier arena passes its soft limit (explosive searches: memory ~ depth x batch). Sharded
         // engines keep 64 k (their outbox is sized by the batch for every peer).
         auto_batch = opt.batch_nodes <= 0;
-        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : (sharded ? 65536 : 262144);
+        // (round 3, slots dealt by ticket: 1 M again for blocks of at most two registers per lane -- partialorder_18 56 -> 50.5 ms;
+        // the wide blocks of the synthetic family keep 256 k: their frontier is depth x batch x 600 B and 1 M costs them 8 %)
+        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : (sharded ? 65536 : (ctx.NK <= 128 ? 1048576 : 262144));
         if (const char *ev = getenv("STCSP_BATCH")) if (atoi(ev) > 0 && auto_batch) batch = atoi(ev);
         {
             size_t free_b = 0, total_b = 0;
