@@ -571,6 +571,15 @@ struct stcsp_engine {
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (!sharded && !(opt.time_limit_s > 0) && !(opt.max_search_nodes > 0)) burst = 32;  // (budgets are checked between bursts)
+        {
+            // HIP runtimes from 7.2 on start the export's asynchronous device-to-host copies only when the search stream's queued
+            // launches have drained (measured with /opt/rocm 7.2's libamdhip64: all of the export's copies ran AFTER the search,
+            // 2.1 ms per partialorder_14 solve instead of 0.26; the 7.0 runtime that PyTorch loads runs them beside it). Short
+            // bursts bound that wait: partialorder_14 solve + export 5.2 -> 4.0 ms there (3.35 with the 7.0 runtime).
+            int rtv = 0;
+            if (burst > 4 && !(opt.flags & STCSP_F_NO_EXPORT) && hipRuntimeGetVersion(&rtv) == hipSuccess && rtv >= 70200000) burst = 4;
+            if (getenv("STCSP_DEBUG")) fprintf(stderr, "[engine] HIP runtime %d, %d launches per burst\n", rtv, burst);
+        }
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_SMALL")) {
             chain_small = std::max(1, atoi(ev));
@@ -1080,6 +1089,8 @@ struct stcsp_engine {
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ev_x[xi], xs));
         ev_x_used[xi] = true;
+        // (having the kernel write the pinned host arrays itself instead of these copies: search 3.05 -> 4.4 ms, the kernel then holds
+        // its wave slots at the speed of the link -- measured again in round 3 with both HIP runtimes, see create())
         HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
         HIPCHK(hipMemcpyAsync(h_odst + streamed, d_odst.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
         HIPCHK(hipMemcpyAsync(h_oval + streamed * N, d_oval.p + streamed * N, M * N * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
