@@ -668,13 +668,14 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     // expanded (its latency disappears behind the node load); kSlotCursors counters deal interleaved tickets.
     {
         const CtlLayout L_(c.world);
-        const int cur = (int)(blockIdx.x % kSlotCursors);
+        const int ncur = min(kSlotCursors, (int)gridDim.x);  // (a grid smaller than the counters: every residue needs a workgroup)
+        const int cur = (int)blockIdx.x % ncur;
         uint32_t *cursor = c.ctl + L_.slotcur0 + cur * CST;
         for (int gw = blockIdx.x * wpb + wib; gw < n_slots;) {
             unsigned ticket = 0;
             if (lane == 0) ticket = atomicAdd(cursor, 1u);
             expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
-            gw = total_waves + (int)rflu(ticket) * kSlotCursors + cur;
+            gw = total_waves + (int)rflu(ticket) * ncur + cur;
         }
     }
 #endif

@@ -174,6 +174,21 @@ def test_engine_synthetic_64x32_timebox(stcsp):
     assert r.counters.fails > 0
 
 
+@pytest.mark.parametrize("blocks", [1, 3, 37])
+def test_engine_tiny_grids_take_every_slot(stcsp, golden, monkeypatch, blocks):
+    """Slots beyond a wavefront's first are dealt by ticket from sixteen interleaved counters (k_expand): with fewer workgroups
+    than counters (STCSP_BLOCKS: a grid of 1, 3 or 37 workgroups instead of the resident 1,536) every slot must still be taken
+    exactly once -- same automaton and node count as the reference."""
+    monkeypatch.setenv("STCSP_BLOCKS", str(blocks))
+    for name in ["partialorder_11", "digitinvader3"]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m)
+        r = e.solve()
+        a, _ = finish(e, r)
+        assert a.canonical_sha256() == golden[name]["canonical_sha256"], name
+        assert r.counters.search_nodes == golden[name]["search"] or golden[name]["fail"] > 0, name
+
+
 def test_engine_pool_growth_paths(stcsp, golden, monkeypatch):
     """Start with tiny device pools (STCSP_SMALL_POOLS): the frontier arena, edge log, state pool
     and hash table all have to grow (realloc / rehash between launch bursts) several times."""
