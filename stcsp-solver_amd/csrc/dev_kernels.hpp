@@ -348,7 +348,18 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch)
         }
         return;
     }
-    const int chunk = p->chunk_r;
+    int chunk = p->chunk_r;
+    int mc = 0;  // sharded: the fullest outbox cursor
+    if (c.sharded) {
+        for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
+        mc = wave_max(mc);
+        // The outbox bounds the round, not the batch: a slot may meet a leaf in every expansion of its chain and all of a region's
+        // slots may send to one owner, so a region takes at most (room / longest chain) nodes. (The outboxes are sized for 4,096
+        // nodes per region whatever the batch: engine.hip create.)
+        const int longest = p->chain_small > p->chain_big ? p->chain_small : p->chain_big;
+        const int room = ((int)p->cand_cap - mc) / longest;
+        if (room < chunk) chunk = (room >= 256 || mc == 0) ? max(room, 0) : 0;  // (no dribbling: a nearly full outbox is full)
+    }
     const int take = cnt < chunk ? cnt : chunk;
     const int maxtake = wave_max(take);
     const long long taken = wave_sum64(take);
@@ -364,12 +375,8 @@ __device__ void plan_next(const Ctx &c, Plan *p, int lane, unsigned next_launch)
     if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)proc * maxtake > p->edge_cap) status = PS_NEED_EDGES;
     if (status == PS_RUN && ns + proc * taken > p->state_cap) status = PS_NEED_STATES;
     if (status == PS_RUN && (ns + proc * taken) * 2 > p->slot_cap) status = PS_NEED_TABLE;
-    if (status == PS_RUN && c.sharded) {
-        int mc = 0;
-        for (int k = lane; k < c.world * R; k += 64) mc = max(mc, (int)ald(&c.ctl[L.cand0 + k * CST]));
-        mc = wave_max(mc);
-        if ((unsigned long long)mc + (unsigned long long)proc * maxtake > p->cand_cap) status = PS_OUTBOX_FULL;  // a slot may meet a leaf in every expansion of its chain
-    }
+    if (status == PS_RUN && c.sharded && (maxtake == 0 || (unsigned long long)mc + (unsigned long long)proc * maxtake > p->cand_cap))
+        status = PS_OUTBOX_FULL;  // no room for even one node per region: the exchange has to empty the outboxes first
     if (status != PS_RUN) {
         if (lane == 0) {
             p->status = status;
@@ -519,7 +526,14 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
         in_base = p->stack[sp - 1].base;
         in_cap = p->stack[sp - 1].cap;
     }
-    const int take = cnt < chunk ? cnt : chunk;
+    int chunk_now = chunk;
+    const int mcw = c.sharded ? wave_max(mc) : 0;
+    if (c.sharded) {  // the outbox bounds the round (see plan_next)
+        const int longest = chain_small > chain_big ? chain_small : chain_big;
+        const int room = ((int)cand_cap - mcw) / longest;
+        if (room < chunk_now) chunk_now = (room >= 256 || mcw == 0) ? max(room, 0) : 0;
+    }
+    const int take = cnt < chunk_now ? cnt : chunk_now;
     const int maxtake = wave_max(take);
     const long long taken = wave_sum64(take);
     const int chain = taken <= (long long)chain_thresh ? chain_small : chain_big;
@@ -532,7 +546,7 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
     if (status == PS_RUN && (unsigned long long)max_edges + (unsigned long long)proc * maxtake > edge_cap) status = PS_NEED_EDGES;
     if (status == PS_RUN && ns + proc * taken > state_cap) status = PS_NEED_STATES;
     if (status == PS_RUN && (ns + proc * taken) * 2 > slot_cap) status = PS_NEED_TABLE;
-    if (status == PS_RUN && c.sharded && (unsigned long long)wave_max(mc) + (unsigned long long)proc * maxtake > cand_cap) status = PS_OUTBOX_FULL;
+    if (status == PS_RUN && c.sharded && (maxtake == 0 || (unsigned long long)mcw + (unsigned long long)proc * maxtake > cand_cap)) status = PS_OUTBOX_FULL;
     if (status != PS_RUN) {
         if (lane == 0) {
             p->status = status;

@@ -537,7 +537,9 @@ struct stcsp_engine {
         auto_batch = opt.batch_nodes <= 0;
         // (round 3, slots dealt by ticket: 1 M again for blocks of at most two registers per lane -- partialorder_18 56 -> 50.5 ms;
         // the wide blocks of the synthetic family keep 256 k: their frontier is depth x batch x 600 B and 1 M costs them 8 %)
-        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : (sharded ? 65536 : (ctx.NK <= 128 ? 1048576 : 262144));
+        // Sharded engines: 256 k too -- their outboxes no longer grow with the batch (the planner bounds a round by the room
+        // the outboxes have left: dev_kernels.hpp plan_next), so the time-boxed synthetic runs as fast sharded as unsharded.
+        int batch = opt.batch_nodes > 0 ? opt.batch_nodes : (sharded ? 262144 : (ctx.NK <= 128 ? 1048576 : 262144));
         if (const char *ev = getenv("STCSP_BATCH")) if (atoi(ev) > 0 && auto_batch) batch = atoi(ev);
         {
             size_t free_b = 0, total_b = 0;
@@ -590,9 +592,10 @@ struct stcsp_engine {
         if (const char *ev = getenv("STCSP_CHAIN_HEAVY")) chain_heavy = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_DEBUG")) dbg_rounds = atoi(ev) >= 2;
         // outbox: [owner][region] x cand_cap records. Unsharded: unused. A slot may meet a leaf in every expansion of its
-        // chain, so a region of an owner's outbox receives up to chain x max-take candidates per launch: an EMPTY outbox
-        // must hold one launch (or the planner would report PS_OUTBOX_FULL for ever).
-        cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * chunk_r, 4096) : 64);
+        // chain, so a region of an owner's outbox receives up to chain x max-take candidates per launch; the planner takes no
+        // more nodes per region than the outboxes have room for (plan_next), so their size is independent of the batch: room
+        // for 4,096 nodes per region and launch (world 8: 3.4 GB at 100-word records).
+        cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * std::min(chunk_r, 4096), 4096) : 64);
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         sync_ctx();
