@@ -636,6 +636,9 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
     if ((int)blockIdx.x * wpb >= n_slots) return;
     const unsigned n_working = (unsigned)min((n_slots + wpb - 1) / wpb, (int)gridDim.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c.progress)  // (the streaming export's "the round before this one has ended")
+        __hip_atomic_store(&c.progress->started, (unsigned long long)(kload(c.plan, (int)(offsetof(Plan, rounds) / 4)) + 1), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
     const unsigned long long t_k0 = PHASE_NOW();
     (void)t_k0;

@@ -94,6 +94,10 @@ enum { ERR_WATCHDOG = 1, ERR_TABLE_SPIN = 2, ERR_EDGE_OVERFLOW = 3, ERR_STATE_OV
 struct Progress {
     unsigned long long edge_seen[R];  // tag << 32 | cursor
     unsigned long long states_seen;   // tag << 32 | count
+    // number of the round whose launch has STARTED (written by its first workgroup): launches of one stream run one after the
+    // other, so the round before it has ENDED -- its snapshot may be shipped now, a whole round earlier than when the next
+    // snapshot shows up
+    unsigned long long started;
 };
 
 struct ImgOff {

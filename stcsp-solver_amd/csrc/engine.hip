@@ -745,14 +745,24 @@ struct stcsp_engine {
         uint32_t edge_seen[R];
         uint32_t states_seen;
     } prog_snap{};
-    bool prog_have = false;
+    bool prog_have = false, prog_sent = false;
     unsigned long long prog_gen = 0;
     int ship_progress() {
         // a snapshot = all words carrying the same tag (= number of the launch that wrote them)
         const volatile unsigned long long *src = (const volatile unsigned long long *)h_progress;
         const unsigned long long s0 = src[R];
         const unsigned long long g = s0 >> 32;
-        if (g == prog_gen) return STCSP_OK;
+        if (g == prog_gen) {
+            // nothing new finalized -- but the NEXT round's launch may have started meanwhile: the round of the snapshot in hand
+            // has ended then (same stream, in order), and the snapshot can go a whole round earlier
+            if (prog_have && !prog_sent && src[R + 1] > prog_gen) {
+                int rc = stream_edges(prog_snap.edge_seen, false);
+                if (rc == STCSP_OK) rc = stream_states(prog_snap.states_seen);
+                if (rc != STCSP_OK) return rc;
+                prog_sent = true;
+            }
+            return STCSP_OK;
+        }
         ProgressSnap s;
         s.states_seen = (uint32_t)s0;
         bool whole = true;
@@ -763,13 +773,14 @@ struct stcsp_engine {
         }
         if (!whole) return STCSP_OK;  // launch g is still writing (or g + 1 already is): look again
         // launch g has finalized, so the launch of the snapshot in hand has ended: its records are in memory
-        if (prog_have) {
+        if (prog_have && !prog_sent) {
             int rc = stream_edges(prog_snap.edge_seen, false);
             if (rc == STCSP_OK) rc = stream_states(prog_snap.states_seen);
             if (rc != STCSP_OK) return rc;
         }
         prog_snap = s;
         prog_have = true;
+        prog_sent = false;
         prog_gen = g;
         return STCSP_OK;
     }
