@@ -806,6 +806,7 @@ struct stcsp_engine {
         streaming = !(opt.flags & (STCSP_F_NO_EXPORT | STCSP_F_KEEP_RAW_EDGES)) && !getenv("STCSP_HOST_EXPORT") &&
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
+        if (const char *sc = getenv("STCSP_STREAM_CHUNK_IDLE")) stream_chunk_idle = (size_t)std::max(1, atoi(sc));
         if (d_sdeg.p) HIPCHK(hipMemsetAsync(d_sdeg.p, 0, d_sdeg.n * sizeof(uint32_t), stream));
         ev_x_used[0] = ev_x_used[1] = false;
         ev_k_used = false;
@@ -1023,6 +1024,7 @@ struct stcsp_engine {
     size_t streamed = 0;                 // edge records staged so far
     uint32_t streamed_r[R] = {0};        // ... per region of the edge log
     size_t stream_chunk_min = 32768;     // records per chunk (except the last)
+    size_t stream_chunk_idle = 2048;     // ... a smaller chunk goes when both export streams are idle
     int ensure_export_capacity(size_t E) {
         const int N = ctx.N;
         if (d_osrc.n < E) {
@@ -1083,7 +1085,12 @@ struct stcsp_engine {
             M += to[r] - streamed_r[r];
         }
         v.pref[R] = (uint32_t)M;
-        if (M == 0 || (!final && M < stream_chunk_min)) return STCSP_OK;
+        if (M == 0) return STCSP_OK;
+        if (!final && M < stream_chunk_min) {
+            // a small chunk waits for more -- unless the link has nothing to do (the narrow rounds at the end of a search: what is
+            // shipped now is not left for after the search)
+            if (M < stream_chunk_idle || hipStreamQuery(xstream) != hipSuccess || hipStreamQuery(xstream2) != hipSuccess) return STCSP_OK;
+        }
         if (streamed + M > 0xfffffff0ull) {  // beyond the 32-bit record indices of the export kernels: compacting path decides
             streaming = false;
             return STCSP_OK;
