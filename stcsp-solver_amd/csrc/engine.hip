@@ -1765,7 +1765,8 @@ struct stcsp_engine {
             lap("first fixpoint round");
         }
         if (quick_final) {
-            { int rcx = sync_xstreams(); if (rcx != STCSP_OK) return rcx; }
+            // (no synchronisation of the export streams: the main stream waited for the events behind their last operations --
+            // every chunk's copies, the key kernel -- and has just been synchronised; two more calls cost ~30 us here)
             live = (uint32_t)E;
             lap("wait for the streamed chunks");
         } else if (E) {
