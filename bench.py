@@ -62,7 +62,7 @@ def launch_ranks(args, argv):
     (they would wait in a collective for ever), and the exit code is the worst of the ranks'."""
     import subprocess
     n = args.gpus
-    if args.test_engine is None:
+    if HOOKS["engine"] is None:
         import torch
         have = torch.cuda.device_count()
         if have < n:
@@ -74,7 +74,7 @@ def launch_ranks(args, argv):
     procs = []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, str(HOOKS["entry"])] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [None] * n
     deadline = None
@@ -92,6 +92,16 @@ def launch_ranks(args, argv):
         time.sleep(0.05)
     bad = [rc for rc in rcs if rc != 0]
     return 0 if not bad else max(abs(rc) for rc in bad) or 1
+
+
+def host_cpu_share():
+    """CPUs this process may run on (the affinity mask: a GPU box hands a job a share of its host cores), and the number of
+    workers the all-cores legs use: the share, capped at 64 (the restatement's shared state table stops scaling there)."""
+    try:
+        share = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        share = os.cpu_count() or 1
+    return share, max(1, min(share, 64))
 
 
 def cpu_baseline(st, name, seconds, threads):
@@ -119,7 +129,7 @@ def cpu_baseline(st, name, seconds, threads):
                      f"{'truncated' if r.truncated else 'complete'}); oracle/ref_dfs.cpp, 1 thread. The reference itself "
                      f"(unbuildable on this box) measured {REFERENCE_P14_NODES_PER_S:.0f} nodes/s on partialorder_14 on the "
                      "survey VM (1 core; it leaks 16 kB per leaf, half of its time is page faults)",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": host_cpu_share()[0]}
     if threads > 1:
         op = Ref(m, time_limit_s=seconds)
         t0 = time.time()
@@ -233,21 +243,15 @@ def synthetic_workload(st, device, seconds, cpu_seconds=0.0, cpu_threads=1):
     return out
 
 
-def make_engine_factory(st, args, local_rank):
-    """The product engine -- or, for the launcher's CPU test only (--test-engine fmodel), the oracle's scalar frontier
-    model over gloo: that leg exists so that the N-rank launcher path can be exercised on a box without GPUs; it is
-    labelled in the output line and is never a default."""
-    if args.test_engine == "fmodel":
-        lib = C.CDLL(str(REPO / "oracle" / "libstcsp_oracle.so"))
-        st.bind_engine_api(lib, "stcsp_fmodel")
+# Injection points for tests/bench_cpu_entry.py (the launcher / N-rank pipeline test on a box without GPUs): a stand-in
+# engine class, the process-group backend that goes with it, the script the launcher starts per rank, and a label that
+# ends up in the output line.  bench.py itself never sets them: run as `python bench.py` the engine is the HIP engine.
+HOOKS = {"engine": None, "backend": "nccl", "entry": Path(__file__).resolve(), "label": None}
 
-        class FModel(st.EngineBase):
-            _prefix = "stcsp_fmodel"
 
-            def __init__(self, model, **o):
-                super().__init__(lib, model, **o)
-
-        return lambda model, **kw: FModel(model, **kw)
+def make_engine_factory(st, local_rank):
+    if HOOKS["engine"] is not None:
+        return lambda model, **kw: HOOKS["engine"](model, **kw)
     return lambda model, **kw: st.Engine(model, device=local_rank, **kw)
 
 
@@ -295,7 +299,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU leg (default: min(host cpus, 16), the box's CPU share)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU legs (default: the CPUs in this process's affinity mask, os.sched_getaffinity, at most 64)")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--synthetic-seconds", type=float, default=2.0)
     ap.add_argument("--synthetic-cpu-seconds", type=float, default=5.0)
@@ -306,8 +310,6 @@ def main():
     ap.add_argument("--share-per-rank", type=int, default=64, help="sharded runs: ... 'enough' = this many open nodes per rank")
     ap.add_argument("--stepped", action="store_true",
                     help="N=1 only: run the sharded pipeline (size-1 RCCL group, STCSP_F_STEPPED) -- the N>1 code path on one GPU")
-    ap.add_argument("--test-engine", choices=["fmodel"], default=None,
-                    help="tests only: drive the launcher + sharded pipeline with the oracle's CPU frontier model over gloo (no GPU)")
     args = ap.parse_args()
 
     if args.synthetic_shape:
@@ -326,7 +328,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    cpu_test = args.test_engine is not None
+    cpu_test = HOOKS["engine"] is not None
     if not cpu_test and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if cpu_test:
@@ -339,7 +341,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
         if cpu_test:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(HOOKS["backend"], rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # a fresh checkout has no built libraries: rank 0 compiles them once, the others wait
@@ -349,7 +351,7 @@ def main():
     if world > 1:
         dist.barrier()
 
-    make_engine = make_engine_factory(st, args, local_rank)
+    make_engine = make_engine_factory(st, local_rank)
     model = st.Model.from_name(args.workload)
     flags = st.F_PROFILE | (st.F_STEPPED if stepped and world == 1 else 0)
     eng = make_engine(model, rank=rank, world=world, flags=flags, batch_nodes=args.batch)
@@ -434,15 +436,23 @@ def main():
     if not stepped:
         # the streamed export (edge log shipped while the search runs, ordered by kernel boundaries: DESIGN 4.4) against
         # the compacting export of one more solve of the same engine (everything copied after the search has ended)
-        os.environ["STCSP_STREAM_EXPORT"] = "0"
-        try:
-            r2 = eng.solve()
-            a2 = eng.automaton(r2).traverse().renumber()
-            check["export_paths"] = {"streamed_sha256": check.get("canonical_sha256"), "compacting_sha256": a2.canonical_sha256(),
-                                     "equal": a2.canonical_sha256() == check.get("canonical_sha256")}
-            parity_ok = parity_ok and check["export_paths"]["equal"]
-        finally:
-            del os.environ["STCSP_STREAM_EXPORT"]
+        prev = os.environ.get("STCSP_STREAM_EXPORT")
+        if prev is not None and prev.strip() == "0":
+            # the caller switched streaming off for the whole run (tools/profile_*.sh): both solves took the compacting path
+            check["export_paths"] = {"skipped": "STCSP_STREAM_EXPORT=0 was set by the caller: the timed steps already used the compacting export"}
+        else:
+            os.environ["STCSP_STREAM_EXPORT"] = "0"
+            try:
+                r2 = eng.solve()
+                a2 = eng.automaton(r2).traverse().renumber()
+                check["export_paths"] = {"streamed_sha256": check.get("canonical_sha256"), "compacting_sha256": a2.canonical_sha256(),
+                                         "equal": a2.canonical_sha256() == check.get("canonical_sha256")}
+                parity_ok = parity_ok and check["export_paths"]["equal"]
+            finally:
+                if prev is None:
+                    del os.environ["STCSP_STREAM_EXPORT"]
+                else:
+                    os.environ["STCSP_STREAM_EXPORT"] = prev
 
     # N>1 (and --stepped): workloads that CAN scale, through the same sharded pipeline, outside the timed region
     scalable = {}
@@ -459,6 +469,9 @@ def main():
                                                                time_limit_s=args.synthetic_seconds, repeats=2, knobs=knobs)
         except sh.ShardedSolveError as ex:  # agreed on every rank
             scalable["error"] = f"{type(ex).__name__}: {ex}"
+        # a scalable workload that failed, or expanded another number of nodes than the unsharded search does, fails the run
+        if "error" in scalable or any(isinstance(v, dict) and v.get("nodes_ok") is False for v in scalable.values()):
+            parity_ok = False
 
     if rank == 0:
         S = res.sig_len
@@ -490,7 +503,7 @@ def main():
                             "wavefront_revisions": wrevs / max(nodes, 1) * (world if stepped else 1), "sweeps": sweeps / max(nodes, 1) * (world if stepped else 1)},
                "sharding": "none" if not stepped else f"state-owner x{world}"}
         if cpu_test:
-            cfg["engine"] = "TEST ONLY: oracle/frontier_model.cpp over gloo (launcher / pipeline check without GPUs; not a measurement of the product)"
+            cfg["engine"] = HOOKS["label"] or "TEST ONLY: injected stand-in engine (not a measurement of the product)"
         if stepped:
             cfg["sharded"] = {"rank_search_nodes_per_step": [r[0] // args.steps for r in rank_rows],
                               "nodes_donated": [r[2] for r in rank_rows], "nodes_adopted": [r[3] for r in rank_rows],
@@ -509,7 +522,7 @@ def main():
             try:
                 others["synthetic_64x32"] = synthetic_workload(st, local_rank, args.synthetic_seconds,
                                                                0.0 if args.no_cpu_baseline else args.synthetic_cpu_seconds,
-                                                               args.cpu_threads or min(os.cpu_count() or 1, 16))
+                                                               args.cpu_threads or host_cpu_share()[1])
             except Exception as ex:
                 others["synthetic_64x32"] = {"error": f"{type(ex).__name__}: {ex}"}
             cfg["other_workloads"] = others
@@ -539,7 +552,7 @@ def main():
             "parity": check,
         }
         if not args.no_cpu_baseline and world == 1 and not stepped:
-            out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds, args.cpu_threads or min(os.cpu_count() or 1, 16))
+            out["cpu_baseline"] = cpu_baseline(st, args.workload, args.cpu_seconds, args.cpu_threads or host_cpu_share()[1])
         print(json.dumps(out), flush=True)
     if stepped:
         ok = torch.tensor([1 if parity_ok else 0], dtype=torch.int64, device=dev)

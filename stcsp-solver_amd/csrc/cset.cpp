@@ -2,6 +2,7 @@
 #include "cset.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <set>
 #include <string>
@@ -136,29 +137,37 @@ void SetManager::finish_set(HostSet &s) {
     s.self_loop = !any_first_or_at;
 }
 
-static uint64_t set_content_hash(const HostSet &s) {
-    std::vector<int32_t> words;
-    for (auto &c : s.cons) serialise_tree(c.root, words);
-    uint64_t h = 1469598103934665603ull;
-    for (int32_t w : words) {
+// Hash of exactly what set_eq / tree_eq compare -- token, num, var and the shape; NOT Tree::arr, which constraintNodeEq
+// (src/constraint.cpp:551-561) ignores: two translated sets that differ only in the array a node indexes are ONE set to the
+// reference's seenConstraints lookup, so they must land in one bucket here (serialise_tree, with arr, is the wire format
+// of sharded runs only).
+static void hash_tree(const Tree *t, uint64_t &h) {
+    auto mix = [&](int32_t w) {
         h ^= (uint32_t)w;
         h *= 1099511628211ull;
+    };
+    if (!t) {
+        mix(-1);
+        return;
     }
+    mix(t->token);
+    mix(t->num);
+    mix(t->var);
+    hash_tree(t->left, h);
+    hash_tree(t->right, h);
+}
+static uint64_t set_content_hash(const HostSet &s) {
+    uint64_t h = 1469598103934665603ull;
+    for (auto &c : s.cons) hash_tree(c.root, h);
     return h;
 }
 
 int SetManager::register_set(std::unique_ptr<HostSet> s) {
     finish_set(*s);
     int idx = (int)sets.size();
-    set_by_hash.emplace(set_content_hash(*s), idx);
-    if (sharded) {
-        std::vector<int32_t> words;
-        for (auto &c : s->cons) serialise_tree(c.root, words);
-        uint64_t h = 1469598103934665603ull;
-        for (int32_t w : words) {
-            h ^= (uint32_t)w;
-            h *= 1099511628211ull;
-        }
+    const uint64_t h = set_content_hash(*s);
+    set_by_hash.emplace(h, idx);
+    if (sharded) {  // (what set_eq compares: shards that meet array-variants of one set agree on its tag)
         int32_t tag = (int32_t)((h ^ (h >> 31)) & 0x3fffffff);
         // The tag must depend on the set's content only (shards discover sets in different orders), so a
         // collision cannot be probed away: it is reported (2^-30 per pair of sets).
@@ -292,10 +301,17 @@ int SetManager::transition(int set, const std::vector<int> &first_vals) {
     return found;
 }
 
-int SetManager::pretranslate(long long max_tuples, int max_sets) {
+int SetManager::pretranslate(long long max_tuples, int max_sets, long long max_total_tuples, double max_seconds) {
     int added = 0;
+    // max_tuples bounds ONE set's capture space; the work of the whole call is bounded too -- every set enumerates its tuples
+    // even when all of them map onto known sets, so thousands of sets x tens of thousands of tuples would be hours of host time.
+    // When either budget runs out the call stops where it is: the sets not finished keep direct = false (the device asks on demand).
+    long long total_left = max_total_tuples > 0 ? max_total_tuples : (1ll << 62);
+    const auto t_start = std::chrono::steady_clock::now();
+    auto out_of_time = [&]() { return max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > max_seconds; };
     for (size_t si = 0; si < sets.size() && (int)sets.size() < max_sets; si++) {  // sets.size() grows while we go
         if (sets[si]->self_loop) continue;
+        if (total_left <= 0 || out_of_time()) break;
         const std::vector<int> fv = sets[si]->first_vars;  // (copy: sets may be re-allocated by transition())
         // Values a leaf can show for each captured variable: a `first` constraint over ONE captured variable and nothing
         // else (first giveTo < 2; first seen3 == 0) is enforced at time 0, so only the values it admits are ever
@@ -330,10 +346,14 @@ int SetManager::pretranslate(long long max_tuples, int max_sets) {
             if (tuples > max_tuples) break;
         }
         if (tuples > max_tuples) continue;
+        if (tuples > total_left) break;  // (the whole set or nothing: a half-enumerated set gains no table)
+        total_left -= tuples;
         if (tuples > 0) {
             std::vector<size_t> pos(fv.size(), 0);
             std::vector<int> vals(fv.size());
+            long long done = 0;
             for (;;) {
+                if ((++done & 255) == 0 && out_of_time()) return added;  // (this set stays direct = false)
                 for (size_t k = 0; k < fv.size(); k++) vals[k] = cand[k][pos[k]];
                 // a tuple that violates one of the set's own `first` constraints is never seen at a leaf (the constraint
                 // is enforced at time 0): its translation -- a set with a false constant constraint -- is not worth a set
@@ -356,15 +376,21 @@ int SetManager::pretranslate(long long max_tuples, int max_sets) {
                     added++;
                     if ((int)sets.size() >= max_sets) return added;
                 }
-                size_t k = 0;  // next tuple (odometer)
-                for (; k < fv.size(); k++) {
-                    if (pos[k] + 1 < cand[k].size()) {
-                        pos[k]++;
+                // next tuple: the LAST captured variable runs fastest, values ascending -- the order in which the reference's
+                // DFS meets the leaves of a state (first unbound variable in queue order bisected first, lower half first:
+                // solver.cpp:41-53, solveralgorithm.cpp:911-939). It matters when two translations differ only in the ARRAY a
+                // node indexes: constraintNodeEq ignores the array (constraint.cpp:551-561), so the reference keeps whichever
+                // of the two its DFS translated first, and every later leaf runs under that one.
+                size_t k = fv.size();
+                while (k > 0) {
+                    if (pos[k - 1] + 1 < cand[k - 1].size()) {
+                        pos[k - 1]++;
                         break;
                     }
-                    pos[k] = 0;
+                    pos[k - 1] = 0;
+                    k--;
                 }
-                if (k == fv.size()) break;
+                if (k == 0) break;
             }
         }
         // every tuple a leaf can show has its transition: the device looks it up in a table indexed by the tuple (when the

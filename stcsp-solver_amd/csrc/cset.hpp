@@ -104,7 +104,7 @@ public:
     // register the transition of every tuple (and so on for the sets this creates, up to `max_sets` sets), so
     // that the device never has to stop for a translation of such a set (models with `first x` inside
     // arithmetic have |D| sets). Returns the number of transitions added, < 0 on error.
-    int pretranslate(long long max_tuples, int max_sets);
+    int pretranslate(long long max_tuples, int max_sets, long long max_total_tuples = 0, double max_seconds = 0);
     int compile(FlatProgram &out);
     int find_tag(int32_t tag) const;
     // serialised registry exchange for sharded runs (every shard must know every set)

@@ -662,7 +662,14 @@ __device__ __forceinline__ void flush_env(const Ctx &c, WaveEnv<DR> &E, int slot
         default: break;
     }
     if (v) atomicAdd(&c.stats[(slot % kStatSlots) * kStatWords + lane], v);
-    if (E.err && lane == 0) atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)E.err);
+    // RETURNING atomic whose result is consumed: the wavefront has then waited for it, so the error word is in place before
+    // the workgroup's barrier and the end-of-round ticket behind it (k_expand) -- finalize_round must not plan another round
+    // over an overflow. (A non-returning atomic is not waited for by the barrier's workgroup-scope release on gfx9.)
+    if (E.err && lane == 0) {
+        const uint32_t old = atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)E.err);
+        asm volatile("" ::"v"(old));
+    }
+    STCSP_REJOIN();
 }
 
 template <int DR>

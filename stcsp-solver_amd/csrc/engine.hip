@@ -111,6 +111,7 @@ struct stcsp_engine {
     int max_blocks = 256 * 4;  // k_expand grid (workgroups): set from the occupancy query
 
     DevBuf<int> d_arr_data, d_arr_off, d_code, d_miss, d_tdirect;
+    std::vector<int32_t> tdirect_dev;  // host copy of what d_tdirect holds (upload_program sends differences only)
     DevBuf<uint32_t> d_state_keys, d_ctl, d_edges, d_arena, d_cand, d_pack, d_img;
     bool img_in_lds = false;
     DevBuf<unsigned long long> d_slots, d_stats;
@@ -325,7 +326,34 @@ struct stcsp_engine {
         o.words = (int)img.size();
         HIPCHK(d_img.upload(img));
         HIPCHK(d_code.upload(prog.code));
-        HIPCHK(d_tdirect.upload(prog.tdirect));  // direct transition tables: one look-up per leaf, may be MBs: not part of the image
+        // direct transition tables: one look-up per leaf, may be MBs (up to 256 MB): not part of the image, and not uploaded as
+        // a whole at every translation stop -- a recompile appends tables and patches a few entries, so only the runs that
+        // differ from the device's copy travel
+        {
+            const std::vector<int32_t> &nt = prog.tdirect;
+            if (nt.size() > d_tdirect.n || !d_tdirect.p) {
+                HIPCHK(hipStreamSynchronize(stream));
+                HIPCHK(d_tdirect.alloc(std::max<size_t>(nt.size() + nt.size() / 2, 1024)));
+                tdirect_dev.clear();
+            }
+            size_t i = 0;
+            while (i < nt.size()) {
+                if (i < tdirect_dev.size() && tdirect_dev[i] == nt[i]) {
+                    i++;
+                    continue;
+                }
+                size_t j = i + 1, same = 0;  // run of differing entries (gaps of < 64 equal ones are not worth a second copy)
+                while (j < nt.size() && same < 64) {
+                    same = (j < tdirect_dev.size() && tdirect_dev[j] == nt[j]) ? same + 1 : 0;
+                    j++;
+                }
+                j -= same;
+                HIPCHK(hipMemcpyAsync(d_tdirect.p + i, nt.data() + i, (j - i) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                i = j;
+            }
+            HIPCHK(hipStreamSynchronize(stream));  // (pageable source)
+            tdirect_dev = nt;
+        }
         ctx.tdirect = d_tdirect.p;
         // bitmaps too big for the host to tabulate: the device fills them in (k_tabulate), once -- the result goes
         // back into the SetManager's table cache, so later compiles place the finished words
@@ -382,11 +410,12 @@ struct stcsp_engine {
             int depth = kSibDepth;
             if (const char *ev = getenv("STCSP_BIG_DEPTH")) depth = std::max(1, std::min(kSibDepth, atoi(ev)));
             size_t scratch_big = 0;
-            for (;; depth--) {  // the deepest sibling stack that still fits
+            for (;; depth--) {  // the deepest sibling stack that still fits (never below 1: a depth of 0 would overlap the wavefronts' regions)
                 scratch_big = (size_t)STCSP_BIG_WAVES * wave_scratch_words(ctx.NK, ctx.stack_slots, true, depth) * sizeof(int);
-                if ((size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024 || depth == 2) break;
+                if ((size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024 || depth <= std::min(2, kSibDepth) || depth <= 1) break;
             }
-            big = (size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024;
+            big = depth >= 1 && (size_t)tables_end * 4 + scratch_big <= (size_t)160 * 1024 &&
+                  scratch_big >= (size_t)STCSP_BIG_WAVES * wave_sib_offset(ctx.NK, ctx.stack_slots, true) * sizeof(int);
             if (big_env) big = big && atoi(big_env) != 0;
             if (big) {
                 img_in_lds = false;
@@ -518,8 +547,14 @@ struct stcsp_engine {
             int max_sets = 16384;      // (node records address at most 65535 sets)
             if (const char *ev = getenv("STCSP_PRETRANSLATE")) tuples = atoll(ev);
             if (const char *ev = getenv("STCSP_PRETRANSLATE_SETS")) max_sets = std::max(1, atoi(ev));
+            // the whole call is bounded as well: 2^20 tuples over all sets, 20 s of host time -- what is left over
+            // is translated on demand. STCSP_PRETRANSLATE_TOTAL / _SECONDS override.
+            long long total = 1ll << 20;
+            double secs = 20.0;
+            if (const char *ev = getenv("STCSP_PRETRANSLATE_TOTAL")) total = atoll(ev);
+            if (const char *ev = getenv("STCSP_PRETRANSLATE_SECONDS")) secs = atof(ev);
             if (tuples > 0) {
-                const int pre = mgr.pretranslate(tuples, max_sets);
+                const int pre = mgr.pretranslate(tuples, max_sets, total, secs);
                 if (pre < 0) return fail(pre, "%s", mgr.error.c_str());
             }
         }

@@ -1,7 +1,7 @@
 """bench.py's own N-rank launcher (`python bench.py --gpus N` without torchrun): the parent starts N rank processes
-BEFORE touching any GPU, waits, prints rank 0's line. On CPU the ranks run the oracle's frontier model over gloo
-(--test-engine fmodel: a labelled test leg, never a default), so the launcher, the rendezvous, the sharded pipeline,
-the N>1 output line and the exit codes are exercised without GPUs."""
+BEFORE touching any GPU, waits, prints rank 0's line. On CPU the ranks run the oracle's frontier model over gloo,
+injected by tests/bench_cpu_entry.py (bench.py has no switch for it), so the launcher, the rendezvous, the sharded
+pipeline, the N>1 output line and the exit codes are exercised without GPUs."""
 import json
 import subprocess
 import sys
@@ -12,8 +12,11 @@ import pytest
 REPO = Path(__file__).resolve().parents[1]
 
 
-def run_bench(*argv, timeout=300):
-    return subprocess.run([sys.executable, str(REPO / "bench.py"), *argv], capture_output=True, text=True, timeout=timeout)
+def run_bench(*argv, timeout=300, entry="bench.py"):
+    return subprocess.run([sys.executable, str(REPO / entry), *argv], capture_output=True, text=True, timeout=timeout)
+
+
+CPU_ENTRY = "tests/bench_cpu_entry.py"
 
 
 def last_json(stdout):
@@ -24,8 +27,8 @@ def last_json(stdout):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_starts_its_own_ranks(oracle_lib, golden, world):
-    r = run_bench("--gpus", str(world), "--test-engine", "fmodel", "--workload", "partialorder_10", "--steps", "1", "--warmup", "0",
-                  "--scalable-workload", "juggling_b4_f5", "--synthetic-seconds", "0")
+    r = run_bench("--gpus", str(world), "--workload", "partialorder_10", "--steps", "1", "--warmup", "0",
+                  "--scalable-workload", "juggling_b4_f5", "--synthetic-seconds", "0", entry=CPU_ENTRY)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == world
@@ -43,9 +46,9 @@ def test_bench_starts_its_own_ranks(oracle_lib, golden, world):
 def test_bench_time_boxed_synthetic_through_the_sharded_pipeline(oracle_lib):
     """The N>1 line carries the time-boxed synthetic workload through solve_sharded (here a 24 x 8 member of the family
     that never reaches a leaf either: the CPU stand-in manages ~3 k nodes/s on 64 x 32): every rank gets work."""
-    r = run_bench("--gpus", "2", "--test-engine", "fmodel", "--workload", "juggling_b4_f5", "--steps", "1", "--warmup", "0",
+    r = run_bench("--gpus", "2", "--workload", "juggling_b4_f5", "--steps", "1", "--warmup", "0",
                   "--scalable-workload", "", "--synthetic-seconds", "20.0", "--synthetic-shape", "24,8,125,4,7",
-                  "--budget-rounds", "1", "--share-per-rank", "2")
+                  "--budget-rounds", "1", "--share-per-rank", "2", entry=CPU_ENTRY)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     s = d["config"]["sharded"]["scalable_workloads"]["synthetic"]
@@ -66,6 +69,14 @@ def test_bench_refuses_more_gpus_than_visible():
 
 def test_bench_world_mismatch_is_an_error():
     import os
-    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--test-engine", "fmodel"], capture_output=True, text=True, timeout=120,
+    r = subprocess.run([sys.executable, str(REPO / CPU_ENTRY), "--gpus", "1"], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_has_no_switch_that_replaces_the_engine():
+    """The benchmark script must not be able to put the checker in the product's place by itself."""
+    src = (REPO / "bench.py").read_text()
+    assert "--test-engine" not in src and "fmodel" not in src
+    r = run_bench("--test-engine", "fmodel", timeout=120)
+    assert r.returncode != 0 and "unrecognized arguments" in r.stderr

@@ -188,3 +188,32 @@ def test_pretranslation_on_the_cpu(stcsp, oracle_lib, RefOracle, FrontierModel, 
         ao = o.automaton(ro).traverse().renumber()
         assert a.canonical_sha256() == ao.canonical_sha256()
         assert r.n_constraint_sets == ro.n_constraint_sets
+
+
+# Two translated constraint sets that differ ONLY in the array a node indexes are one set to the reference
+# (constraintNodeEq, src/constraint.cpp:551-561, compares token / num / var and the shape, not the array): the set its DFS
+# translated first stands for both.  The product's set registry must merge them too (content hash over what set_eq compares)
+# and its ahead-of-need translation must meet the tuples in the DFS's leaf order, or the automaton differs.
+TWO_ARRAYS = ("arr A:{0,1}; arr B:{1,0}; var p:[0,1]; var q:[0,1]; var z:[0,1]; "
+              "((first p) and A[z]) == 0; ((first q) and B[z]) == 0; next p == p; next q == q;")
+
+
+@pytest.mark.parametrize("pretranslate", [False, True])
+def test_sets_that_differ_only_in_the_array_are_one_set(stcsp, oracle_lib, RefOracle, FrontierModel, pretranslate):
+    import ctypes as C
+    m = stcsp.Model(text=TWO_ARRAYS)
+    o = RefOracle(m)
+    ro = o.solve()
+    ao, _ = finish(o, ro)
+    f = FrontierModel(m)
+    if pretranslate:
+        oracle_lib.stcsp_fmodel_pretranslate.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+        ns, nd, te = C.c_int(), C.c_int(), C.c_longlong()
+        assert oracle_lib.stcsp_fmodel_pretranslate(f._h, 65536, 16384, C.byref(ns), C.byref(nd), C.byref(te)) >= 1
+        assert ns.value == 4  # initial, {}, {c'}, {c1', c2'} (no leaf ever shows p = q = 1: the DFS never translates it) -- not 5
+    r = f.solve()
+    a, _ = finish(f, r)
+    assert ro.n_constraint_sets == 3 and r.n_constraint_sets == (4 if pretranslate else 3)
+    assert a.canonical() == ao.canonical()
+    # the merged set really is the one over B (z = 1 on the self-loops of BOTH one-constraint states), as in the reference
+    assert "E 2 2 0 1 1 0 1" in ao.canonical() and "E 3 3 1 0 1 1 0" in ao.canonical()
