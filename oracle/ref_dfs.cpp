@@ -470,6 +470,12 @@ struct Oracle {
     // validate (solveralgorithm.cpp:428-431)
     bool validate(const Con *c) {
         ctr.evaluations++;
+        // (time-boxed runs only: a single support search over wide domains can take minutes; once the box is spent every
+        // search ends as "supported" and the run is reported truncated -- its automaton is not used)
+        if (time_limit > 0) {
+            if ((ctr.evaluations & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) stop = true;
+            if (stop) return true;
+        }
         bool valid = true;
         return eval(c->root, valid) != 0;
     }

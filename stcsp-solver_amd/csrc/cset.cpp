@@ -206,6 +206,11 @@ int SetManager::init(const stcsp_problem *p, bool sharded_tags) {
             error = "variable with empty domain";
             return STCSP_E_INVALID;
         }
+    {
+        long long widest = 1;
+        for (int v = 0; v < N; v++) widest = std::max(widest, (long long)ub[v] - (long long)lb[v] + 1);
+        W = widest <= 32 ? 1 : (widest <= 64 ? 2 : (widest <= 128 ? 4 : 0));
+    }
     array_off.assign(1, 0);
     for (int a = 0; a < p->n_arrays; a++) {
         arrays.elements.emplace_back(p->array_data + p->array_off[a], p->array_data + p->array_off[a + 1]);
@@ -628,7 +633,7 @@ void SetManager::build_entry(const HostCon &c, TableEntry &e) {
     for (int j = 1; j < s; j++)
         if (size[j] > size[w]) w = j;
     long long rows = product / size[w];
-    if (s <= 4 && rows <= kSmallMaxRows) {
+    if (W == 1 && s <= 4 && rows <= kSmallMaxRows) {
         std::vector<int> others;
         for (int j = 0; j < s; j++)
             if (j != w) others.push_back(j);
@@ -828,7 +833,7 @@ int SetManager::compile(FlatProgram &out) {
                         }
                         return nxt[(size_t)w * 2] == 0 || nxt[(size_t)w * 2 + 1] == 0;
                     };
-                    if (side_free(wx, 0u) && side_free(wy, 1u)) {
+                    if (W == 1 && side_free(wx, 0u) && side_free(wy, 1u)) {
                         auto put = [&](int w, int partner, uint32_t side) {
                             const size_t k = nxt[(size_t)w * 2] == 0 ? 0 : 1;
                             nxt[(size_t)w * 2 + k] = (uint32_t)(partner + 1) | (uint32_t)(sh + 64) << 16 | side << 24;
@@ -846,7 +851,8 @@ int SetManager::compile(FlatProgram &out) {
                     it.idx[0] = p * N + c.x;
                     it.idx[1] = (p + 1) * N + c.y;
                     it.aux = lb[c.x] - lb[c.y];
-                    small_items.push_back(it);
+                    if (W > 1) it.aux = std::max(-128, std::min(128, it.aux));  // (a shift beyond the widest domain empties both sides anyway)
+                    (W > 1 ? wave_items : small_items).push_back(it);
                 }
             } else if (c.type == CT_UNTIL) {
                 ItemDesc it{};
@@ -856,7 +862,7 @@ int SetManager::compile(FlatProgram &out) {
                 it.idx[0] = c.x;
                 it.idx[1] = c.y;
                 it.aux = c.until_ordinal;
-                small_items.push_back(it);
+                (W > 1 ? wave_items : small_items).push_back(it);
             } else if (c.type == CT_POINT && !c.scope.empty()) {
                 // identical constraints (e.g. the same constraint in two sets, or the same one at the next compile)
                 // share their tables: table_cache holds the tabulated form, `placed` its position in this image

@@ -93,6 +93,10 @@ public:
     std::multimap<uint64_t, int> set_by_hash;  // content hash -> set index (constraintQueueEq decides; the hash only finds candidates)
     std::string error;
     std::map<std::vector<int32_t>, TableEntry> table_cache;
+    // Bitset words per (variable, time point): 1 while every variable has at most 32 values, else 2 (<= 64) or 4 (<= 128).
+    // Programs compiled for W > 1 have no lane-revised items and no eager arcs: X == next Y, until and point constraints are
+    // all wavefront-revised items (device: dev_wide.hpp). 0: some variable is wider than 128 values (no bitset path).
+    int W = 1;
     bool device_tabulation = false;  // products in (kBitmapMaxBits, kBitmapMaxBitsDevice] become bitmaps filled in by the device
     void store_tabulated(const std::vector<int32_t> &key, const uint32_t *words, size_t n, long long product);
 

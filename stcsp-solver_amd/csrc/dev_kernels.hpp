@@ -3,6 +3,7 @@
 // rehash and the export kernels. Included by engine.hip only.
 #pragma once
 #include "dev_propagate.hpp"
+#include "dev_wide.hpp"
 namespace stcsp {
 namespace dev {
 // ------------------------------------------------------------------ k_expand (round-based)
@@ -32,7 +33,7 @@ __device__ __forceinline__ Ctx ctx_from(const uint32_t (&hot)[2]) {
 // accesses are LDS instructions whatever the compiler can or cannot infer about a pointer into it
 extern __shared__ __attribute__((aligned(16))) int stcsp_lds[];
 
-template <int DR, bool L, bool CS, bool LITE>
+template <int DR, bool L, bool CS, bool LITE, int W = 1>
 __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk, int *ldom,
                             int sib_off, WaveEnv<DR> &env) {
     const Ctx c0 = ctx_from(hot);
@@ -115,6 +116,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
     };
     for (int step = 1;; step++) {
         BranchOut bo;     // outputs of this expansion only (nothing of them is carried round the loop)
+        BranchOutWide bow;  // (W > 1: dev_wide.hpp)
         LeafOut<DR> lo;
         sd = rfl(sd);
         // The header is wave-uniform, but values carried round a loop whose exits the compiler cannot
@@ -130,11 +132,15 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         int oc;
         {
             const Ctx cn = ctx_from(hot);
-            oc = process_node<DR, L, CS, LITE>(cn, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
+            if constexpr (W > 1)
+                oc = process_node_wide<DR, W, L>(cn, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bow, lo);
+            else
+                oc = process_node<DR, L, CS, LITE>(cn, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
         }
         const Ctx ce = ctx_from(hot);
         const Ctx &c = ce;
 #elif STCSP_CTX_REBUILDS == 1
+        static_assert(W == 1, "tuning builds: one-word domains only");
         const Ctx ce = ctx_from(hot);
         const Ctx &c = ce;
         const int oc = process_node<DR, L, CS, LITE>(c, P, lane, lds_vals, lds_stk, ldom, dom, hd, gw, env, bo, lo);
@@ -184,10 +190,24 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
     }
         if (oc == OC_FAIL) STCSP_PATH_END();
         if (oc == OC_BRANCH) {
-            const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bo.bvar + 1) << 16);
+            const int bvar = W > 1 ? bow.bvar : bo.bvar;
+            const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bvar + 1) << 16);
             Dom<DR> child = dom;
-            child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: waits on the sibling stack, or goes to the frontier
-            dom.set(bo.bvar, bo.D & bo.lowmask, lane);     // lower half: next in the chain, or stored too
+            if constexpr (W > 1) {
+                // the bisection point falls into one chunk of the variable: chunks below it go to the lower child whole, those above to the upper one
+                const int NK1 = c.N * c.K;
+#pragma unroll
+                for (int ch = 0; ch < W; ch++) {
+                    const int wi = ch * NK1 + bvar, rel = bow.mid - 32 * ch;
+                    const uint32_t Dc = dom.get(wi);
+                    const uint32_t lowmask = rel >= 31 ? 0xffffffffu : (rel < 0 ? 0u : ((2u << rel) - 1u));
+                    child.set(wi, Dc & ~lowmask, lane);
+                    dom.set(wi, Dc & lowmask, lane);
+                }
+            } else {
+                child.set(bo.bvar, bo.D & ~bo.lowmask, lane);  // upper half: waits on the sibling stack, or goes to the frontier
+                dom.set(bo.bvar, bo.D & bo.lowmask, lane);     // lower half: next in the chain, or stored too
+            }
             if (use_sib && !last && sd < c.sib_depth) {
                 const int sb = sib_off + sd * c.NS;
                 if (lane < 4) stcsp_lds[sb + lane] = (int)(lane == 0 ? hd.h0 : (lane == 1 ? hd.h1 : (lane == 2 ? cw2 : hd.expire)));
@@ -198,7 +218,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
                 }
                 STCSP_REJOIN();
                 sd++;
-                hd.seed = (uint32_t)(bo.bvar + 1);
+                hd.seed = (uint32_t)(bvar + 1);
                 continue;
             }
             if (last) {  // both children and the waiting siblings
@@ -216,7 +236,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
                 return;
             }
             store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, cw2, hd.expire, child, lane);
-            hd.seed = (uint32_t)(bo.bvar + 1);
+            hd.seed = (uint32_t)(bvar + 1);
             continue;
         }
         if (oc == OC_MISS) {  // park the (propagated) node again until the host has translated the set
@@ -619,7 +639,7 @@ __global__ void k_close_segment(Ctx c) {
 #ifndef STCSP_BIG_WAVES
 #define STCSP_BIG_WAVES 16  // wavefronts of a big workgroup
 #endif
-template <int DR, bool L, bool CS, bool LITE, bool BIG = false>
+template <int DR, bool L, bool CS, bool LITE, bool BIG = false, int W = 1>
 __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : STCSP_WIDE_WAVES)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -677,7 +697,7 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
 #pragma unroll
     for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
 #ifdef STCSP_STATIC_SLOTS
-    for (int gw = blockIdx.x * wpb + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+    for (int gw = blockIdx.x * wpb + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE, W>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
 #else
     // Slots: the first one by position, every further one by ticket -- slots differ widely in cost (a chain of up to `chain`
     // expansions, each anything between a failed sweep and a leaf with a new state), and with a fixed stride the round waits for
@@ -691,7 +711,7 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
         for (int gw = blockIdx.x * wpb + wib; gw < n_slots;) {
             unsigned ticket = 0;
             if (lane == 0) ticket = atomicAdd(cursor, 1u);
-            expand_node<DR, L, CS, LITE>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+            expand_node<DR, L, CS, LITE, W>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
             gw = total_waves + (int)rflu(ticket) * ncur + cur;
         }
     }
@@ -993,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_donate(Ctx c, DonateArgs a, uint32_t *o
         if (gw >= a.pref[r + step]) r += step;
     const uint32_t i = gw - a.pref[r];
     const uint32_t *node = c.arena + a.seg_base + ((size_t)r * a.seg_cap + (size_t)(a.count[r] - 1 - (int)i)) * c.NS;
-    const int TS = xfer_stride(c.N, c.K);
+    const int TS = xfer_stride(c.N, c.K * c.W);
     uint32_t *rec = out + (size_t)gw * TS;
     const uint32_t w2 = node[2];
     const uint32_t tag = (uint32_t)kload(c.img, c.o.sets + (int)(w2 & 0xffffu) * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
@@ -1007,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_adopt(Ctx c, const uint32_t *recs, long
     if (gw >= total) return;
     const CtlLayout L(c.world);
     const Plan *p = c.plan;
-    const int TS = xfer_stride(c.N, c.K);
+    const int TS = xfer_stride(c.N, c.K * c.W);
     const uint32_t *rec = recs + (size_t)gw * TS;
     const uint32_t tag = rec[2];
     int set = -1;

@@ -133,7 +133,7 @@ struct Ctx {
     // ---- beyond word 63: general wavefront revisions and diagnostics only
     int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
     int sib_depth;                   // node records on a wavefront's sibling stack (kSibDepth; 2 under the big-workgroup variant)
-    int pad1;
+    int W;                           // bitset words per (variable, time point): 1, or 2 / 4 for domains of up to 64 / 128 values (NK = W*N*K)
     const int *code;
     const int *arr_data;
     const int *tdirect;  // direct transition tables (SetDesc::trans_count < 0): one look-up per leaf, kept out of the LDS-staged image

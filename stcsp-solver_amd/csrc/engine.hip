@@ -223,6 +223,11 @@ struct stcsp_engine {
         if (e_ != hipSuccess) return fail(STCSP_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+    // chunk c (values lb + 32 c ...) of variable v's initial domain [lb, ub]
+    uint32_t init_chunk(int v, int c) const {
+        const long long left = (long long)mgr.ub[v] - (long long)mgr.lb[v] + 1 - 32ll * c;
+        return left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
+    }
     int upload_program() {
         int rc = mgr.compile(prog);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
@@ -241,6 +246,7 @@ struct stcsp_engine {
                 interpreted = interpreted || cd.bitmap_off < 0;
             }
         if (const char *ev = getenv("STCSP_LITE")) lite = lite && atoi(ev) != 0;  // tuning switch
+        if (mgr.W > 1) lite = false;  // (wide domains: every item is revised by dev_wide.hpp's bounds propagation)
         // one contiguous image; every section starts on a 16-byte boundary
         std::vector<uint32_t> img;
         ImgOff o{};
@@ -253,11 +259,9 @@ struct stcsp_engine {
             if (bytes) memcpy(img.data() + off, data, bytes);
             return off;
         };
-        std::vector<uint32_t> init(ctx.N);
-        for (int v = 0; v < ctx.N; v++) {
-            int w = mgr.ub[v] - mgr.lb[v] + 1;
-            init[v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
-        }
+        std::vector<uint32_t> init((size_t)ctx.N * mgr.W);  // chunk-major: init[c * N + v]
+        for (int c = 0; c < mgr.W; c++)
+            for (int v = 0; v < ctx.N; v++) init[(size_t)c * ctx.N + v] = init_chunk(v, c);
         // Sections in the order of how much a node needs them: what every node reads (the lane-per-item sweep
         // reads `sweep` and `itemrows` with per-lane addresses), then what wavefront revisions read before they can
         // start (item records, scopes, strides, the bytecode: small, and every read of them sits in a dependent
@@ -397,7 +401,7 @@ struct stcsp_engine {
         const size_t scratch = (size_t)4 * wave_scratch_words(ctx.NK, ctx.stack_slots, lite, ctx.sib_depth) * sizeof(int);
         if (scratch > 160 * 1024) return fail(STCSP_E_UNSUPPORTED, "expression stack too deep for LDS");
         // stage the image in LDS when image + scratch leave room for >= 2 workgroups per CU
-        img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024;
+        img_in_lds = (size_t)o.words * 4 + scratch <= 64 * 1024 && mgr.W == 1;  // (the wide kernels exist in the partly-staged form only)
         if (const char *ev = getenv("STCSP_IMG_LDS")) img_in_lds = img_in_lds && atoi(ev) != 0;  // tuning switch
         ctx.stage_words = img_in_lds ? o.words : 0;
         lds_bytes = scratch + (size_t)ctx.stage_words * 4;
@@ -490,13 +494,16 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
         mgr.device_tabulation = !(getenv("STCSP_DEVICE_TABULATE") && atoi(getenv("STCSP_DEVICE_TABULATE")) == 0);
         const int N = mgr.N, K = mgr.K;
+        // domains of up to 32 values take one bitset word per (variable, time point), up to 64 two, up to 128 four (W; one W
+        // for the whole block: dev_wide.hpp); the block of N*K*W words lives in at most kMaxDomRegs registers per lane
         for (int v = 0; v < N; v++) {
             long long width = (long long)mgr.ub[v] - (long long)mgr.lb[v] + 1;
-            if (width > 32)
-                return fail(STCSP_E_UNSUPPORTED, "variable %d has %lld values; this engine packs at most 32 per bitset word", v, width);
+            if (width > 128)
+                return fail(STCSP_E_UNSUPPORTED, "variable %d has %lld values; this engine packs at most 128 (four bitset words) per variable and time point", v, width);
         }
-        if ((long long)N * K > 64 * kMaxDomRegs)
-            return fail(STCSP_E_UNSUPPORTED, "N*K = %d exceeds the %d-word register-resident block", N * K, 64 * kMaxDomRegs);
+        const int W = mgr.W;
+        if ((long long)N * K * W > 64 * kMaxDomRegs)
+            return fail(STCSP_E_UNSUPPORTED, "N*K*W = %d*%d*%d exceeds the %d-word register-resident block", N, K, W, 64 * kMaxDomRegs);
         if (mgr.n_until_cons > 32) return fail(STCSP_E_UNSUPPORTED, "more than 32 until constraints");
         if (1 + mgr.n_sig + mgr.n_until_cons > 64) return fail(STCSP_E_UNSUPPORTED, "signature longer than 63 words");
         int ndev = 0;
@@ -525,13 +532,14 @@ struct stcsp_engine {
         L = CtlLayout(opt.world);
         ctx.N = N;
         ctx.K = K;
-        ctx.NK = N * K;
-        ctx.NS = node_stride(N, K);
+        ctx.NK = N * K * W;  // block words (chunk-major for W > 1: word(c, p, v) = c*N*K + p*N + v)
+        ctx.W = W;
+        ctx.NS = node_stride(N, K * W);
         ctx.sig_len = mgr.n_sig + mgr.n_until_cons;
         ctx.n_sig = mgr.n_sig;
         ctx.n_until_cons = mgr.n_until_cons;
         ctx.KL = 1 + ctx.sig_len;
-        ctx.CS = cand_stride(N, K, ctx.sig_len);
+        ctx.CS = cand_stride(N, K * W, ctx.sig_len);
         ctx.ES = edge_stride(N);
         ctx.world = opt.world;
         ctx.sharded = sharded ? 1 : 0;
@@ -558,7 +566,7 @@ struct stcsp_engine {
                 if (pre < 0) return fail(pre, "%s", mgr.error.c_str());
             }
         }
-        DR = (N * K + 63) / 64;
+        DR = (N * K * W + 63) / 64;
         if (DR == 3) DR = 4;
         HIPCHK(d_arr_data.upload(mgr.array_data));
         ctx.arr_data = d_arr_data.p;
@@ -631,6 +639,7 @@ struct stcsp_engine {
         // more nodes per region than the outboxes have room for (plan_next), so their size is independent of the batch: room
         // for 4,096 nodes per region and launch (world 8: 3.4 GB at 100-word records).
         cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * std::min(chunk_r, 4096), 4096) : 64);
+        if (const char *ev = getenv("STCSP_CAND_CAP")) if (sharded && atoi(ev) > 0) cand_cap = (uint32_t)std::max(atoi(ev), 2 * std::max(chain_small, chain_big));  // tests: outboxes that fill up
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         sync_ctx();
@@ -893,11 +902,9 @@ struct stcsp_engine {
             n_states = 1;
             // root search node: initial domains at every point (variable.cpp:24-29), set 0
             for (int i = 0; i < ctx.NS; i++) node[i] = 0u;
-            for (int p = 0; p < ctx.K; p++)
-                for (int v = 0; v < ctx.N; v++) {
-                    int w = mgr.ub[v] - mgr.lb[v] + 1;
-                    node[4 + p * ctx.N + v] = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
-                }
+            for (int c = 0; c < ctx.W; c++)
+                for (int p = 0; p < ctx.K; p++)
+                    for (int v = 0; v < ctx.N; v++) node[4 + c * ctx.N * ctx.K + p * ctx.N + v] = init_chunk(v, c);
             HIPCHK(hipMemcpyAsync(d_arena.p, node, ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             h_plan->sp = 1;
             h_plan->stack[0].base = 0;
@@ -956,6 +963,8 @@ struct stcsp_engine {
     template <int DRT>
     const void *expand_fn() const {
         const void *fn = nullptr;
+        if (mgr.W == 2) return (const void *)k_expand<DRT, false, false, false, false, 2>;
+        if (mgr.W > 2) return (const void *)k_expand<DRT, false, false, false, false, 4>;
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
             fn = (const void *)k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
@@ -976,6 +985,14 @@ struct stcsp_engine {
     template <int DRT>
     void launch_expand() {
         const Ctx *cp = (const Ctx *)d_ctx.p;
+        if (mgr.W == 2) {
+            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 2>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+            return;
+        }
+        if (mgr.W > 2) {
+            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 4>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+            return;
+        }
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
             if constexpr ((V & 5) == 5)
@@ -999,6 +1016,7 @@ struct stcsp_engine {
     }
     int propagate(int set, uint32_t expire, uint32_t *blocks, int64_t count, int32_t *outcome, int64_t *skipped) {
         if (sharded) return fail(STCSP_E_STATE, "propagate is for unsharded engines");
+        if (mgr.W > 1) return fail(STCSP_E_UNSUPPORTED, "propagate: the node-level seam takes one-word blocks (every domain <= 32 values)");
         if (set < 0 || set >= (int)prog.sets.size() || count < 0 || count > (1 << 24) || !blocks || !outcome)
             return fail(STCSP_E_INVALID, "propagate: bad arguments (set %d of %zu, count %lld)", set, prog.sets.size(), (long long)count);
         if (count == 0) return STCSP_OK;
@@ -1552,7 +1570,7 @@ struct stcsp_engine {
         if (sp <= 0) return STCSP_OK;
         h_stack.resize((size_t)sp);
         HIPCHK(hipMemcpy(h_stack.data(), &d_plan.p->stack[0], (size_t)sp * sizeof(DevSegment), hipMemcpyDeviceToHost));
-        const int TS = xfer_stride(ctx.N, ctx.K);
+        const int TS = xfer_stride(ctx.N, ctx.K * ctx.W);
         if (d_xfer.n < (size_t)want * TS) HIPCHK(d_xfer.alloc((size_t)want * TS));
         if ((rc = flush_ctx())) return rc;
         int64_t done = 0;
@@ -2096,7 +2114,7 @@ int stcsp_engine_set_expand_budget(stcsp_engine *e, int64_t max_rounds, int64_t 
     e->step_min_open = min_open;
     return STCSP_OK;
 }
-int stcsp_engine_node_bytes(const stcsp_engine *e) { return e ? xfer_stride(e->ctx.N, e->ctx.K) * 4 : STCSP_E_INVALID; }
+int stcsp_engine_node_bytes(const stcsp_engine *e) { return e ? xfer_stride(e->ctx.N, e->ctx.K * e->ctx.W) * 4 : STCSP_E_INVALID; }
 int stcsp_engine_donate(stcsp_engine *e, int64_t want, void **ptr, int64_t *count) {
     if (!e || !ptr || !count) return STCSP_E_INVALID;
     return e->donate(want, ptr, count);

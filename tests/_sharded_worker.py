@@ -114,6 +114,12 @@ def run(rank, world, port, name, backend_kind, out_path, prefix_k=2):
                    donated=[e[1] for e in everyone], adopted=[e[2] for e in everyone], canonical=a.canonical() if a.n_states <= 4096 else None)
         if backend_kind == "hip-nccl":
             out["stepped_ms"] = stepped_ms
+        if os.environ.get("STCSP_TEST_ADVERSARIAL"):
+            # solverSolve's tail with -a (solveralgorithm.cpp:972-985) on the merged automaton
+            b = st.Automaton(m, res).traverse()
+            out["adver1"] = b.adversarial(5)
+            b.renumber()
+            out["adv_empty"] = b.canonical().endswith("EMPTY\n")
         Path(out_path).write_text(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

@@ -92,3 +92,65 @@ class Gen:
 
 def random_model(seed: int) -> str:
     return Gen(seed).model()
+
+
+class WideGen(Gen):
+    """The same language over domains of 33..128 values (bitset blocks of two and four words per variable: the engine's
+    W = 2 / 4 kernels): one or two wide variables, the others small, constants that reach into the wide ranges, and
+    transitions that walk through them so that the automata are not trivial."""
+
+    def atom(self):
+        k = self.r.below(100)
+        if k < 50:
+            return self.var()
+        if k < 62:
+            return str(self.r.below(4))
+        if k < 72:
+            return str(self.r.below(self.span))
+        if k < 84:
+            return f"next {self.var()}"
+        if k < 92:
+            return f"first {self.var()}"
+        return f"({self.var()} fby {self.var()})"
+
+    def model(self):
+        n = 2 + self.r.below(2)
+        n_wide = 1 + self.r.below(2)
+        out = []
+        self.span = 33 + self.r.below(96 if self.chance(50) else 32)  # 33..64 (W = 2) or 33..128 (W = 4)
+        for i in range(n):
+            lo = self.r.below(3) - 1
+            hi = lo + (self.span - 1 if i < n_wide else self.r.below(4))
+            self.vars.append(f"v{chr(97 + i)}")
+            out.append(f"var {self.vars[-1]} : [{lo}, {hi}];")
+        if self.chance(25):
+            self.arr_len = 2 + self.r.below(3)
+            out.append("arr T : {" + ", ".join(str(self.r.below(4)) for _ in range(self.arr_len)) + "};")
+        w = self.vars[0]
+        step = 1 + self.r.below(5)
+        k = self.r.below(100)
+        if k < 70:  # the wide variable walks: few successors per state, many states
+            out.append(f"first {w} == {self.r.below(3)};")
+            if self.chance(50):
+                out.append(f"next {w} == (if ({w} ge {self.span - step - 2}) then {self.r.below(3)} else ({w} + {step}));")
+            else:
+                out.append(f"next {w} >= {w} + {step - 1};")
+                out.append(f"next {w} <= {w} + {step};")
+        elif k < 85:
+            out.append(f"next {w} {self.pick(['==', '>=', '<='])} {self.expr(1)};")
+        if n_wide > 1:  # tie the second wide variable to the first, or it multiplies every state's edges by its whole domain
+            d = self.r.below(4)
+            out.append(f"{self.vars[1]} {self.pick(['==', '<=', '>='])} {w} {self.pick(['+', '-'])} {d};")
+            if self.chance(70):
+                out.append(f"{self.vars[1]} {self.pick(['>=', '<='])} {w} {self.pick(['+', '-'])} {self.r.below(3)};")
+        for _ in range(1 + self.r.below(2)):
+            if self.chance(6):
+                out.append(f"{self.var()} until {self.var()};")
+                continue
+            op = self.pick(["==", "!=", "<", ">", "<=", ">=", "->"])
+            out.append(f"{self.expr(1)} {op} {self.expr(2)};")
+        return "\n".join(out) + "\n"
+
+
+def random_wide_model(seed: int) -> str:
+    return WideGen(seed).model()

@@ -381,3 +381,18 @@ def test_engine_thousands_of_constraint_sets_without_stopping(stcsp, RefOracle, 
     assert 1 <= r2.counters.translation_stops <= 32
     a2, _ = finish(e2, r2)
     assert a2.canonical_sha256() == ao.canonical_sha256()
+
+
+def test_engine_merges_sets_that_differ_only_in_the_array(stcsp, RefOracle):
+    """constraintNodeEq (src/constraint.cpp:551-561) ignores the array a node indexes: two translations that differ only
+    there are ONE constraint set to the reference, the one its DFS met first. Same automaton on the engine (whose
+    ahead-of-need translation meets the captured tuples in the DFS's leaf order)."""
+    from test_oracle import TWO_ARRAYS
+    m = stcsp.Model(text=TWO_ARRAYS)
+    o = RefOracle(m)
+    ao, _ = finish(o, o.solve())
+    e = stcsp.Engine(m)
+    r = e.solve()
+    a, _ = finish(e, r)
+    assert a.canonical() == ao.canonical()
+    assert r.counters.translation_stops == 0

@@ -281,3 +281,34 @@ def test_sharded_pipeline_rccl_world1(golden, tmp_path, name):
     assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
     assert r["dom"] == g["dom"]
     print(f"{name}: sharded pipeline on one GPU: {r['rounds']} supersteps, {r['stepped_ms']:.2f} ms")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["partialorder_14", "digitinvader9"])
+def test_sharded_headline_workloads_two_hip_shards_one_gpu(golden, tmp_path, name):
+    """BASELINE's metric instance (partialorder_14 "at 1/2/4/8") and config 5 (digitinvader9 -a on 8 GPUs) through the sharded
+    pipeline with two HIP-engine shards on one GPU: the reference's canonical automaton and `dom`, what one shard donates the
+    other adopts; digitinvader9 also through the merged -a pass (adver1 == 0 and an empty body, as the reference prints)."""
+    env = {"STCSP_TEST_ADVERSARIAL": "1"} if name == "digitinvader9" else {}
+    r = launch(2, name, "hip", tmp_path, env=env, timeout=900)
+    g = golden[name]
+    assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+    assert r["dom"] == g["dom"]
+    assert r["nodes"] == g["search"] and sum(r["rank_nodes"]) == g["search"]
+    assert all(n > 0 for n in r["rank_nodes"])
+    assert sum(r["donated"]) == sum(r["adopted"])
+    if name == "digitinvader9":
+        assert r["adver1"] == 0 and r["adv_empty"]
+
+
+@pytest.mark.gpu
+def test_bursts_that_end_at_planner_stops_with_a_second_engine_on_the_gpu(golden, tmp_path):
+    """The regime of round 3's late-workgroup race: bursts of launches that run past a planner stop (tiny pools: every pool
+    grows again and again; outboxes of 64 candidates: PS_OUTBOX_FULL after a few nodes per region) while a second engine process
+    shares the GPU. Exactly one launch may be admitted per planned round (Plan::gate): parity, and nothing lost or duplicated."""
+    name = "partialorder_12"
+    r = launch(2, name, "hip", tmp_path, env={"STCSP_SMALL_POOLS": "1", "STCSP_CAND_CAP": "64", **SHARE}, timeout=900)
+    g = golden[name]
+    assert (r["states"], r["edges"], r["sha"]) == (g["states"], g["edges"], g["canonical_sha256"])
+    assert r["dom"] == g["dom"] and r["nodes"] == g["search"]
+    assert sum(r["donated"]) == sum(r["adopted"]) > 0
