@@ -148,7 +148,9 @@ def alg_bytes(model, res_sig_len, nodes, leaves):
     + per leaf: key probe + key store + edge record."""
     p = model.problem.contents
     N, K = p.n_vars, p.prefix_k
-    b_node = 2 * N * K * 1 * 4
+    widest = max(p.var_ub[i] - p.var_lb[i] + 1 for i in range(N))
+    W = 1 if widest <= 32 else (2 if widest <= 64 else 4)  # bitset words per (variable, time point): the engine's W (dev_wide.hpp)
+    b_node = 2 * N * K * W * 4
     b_leaf = 4 * (res_sig_len + 1) * 2 + 8 + 4 * N
     return nodes * b_node + leaves * b_leaf, b_node, b_leaf
 

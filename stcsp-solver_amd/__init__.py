@@ -542,6 +542,136 @@ class Engine(EngineBase):
         return b, outcome, skipped.value
 
 
+# ------------------------------------------------------------------ native sharded solve (include/stcsp_sharded.h)
+class ShardedOptions(C.Structure):
+    _fields_ = [("budget_rounds", C.c_int64), ("share_per_rank", C.c_int64), ("max_supersteps", C.c_int64)]
+
+
+class ShardedStats(C.Structure):
+    _fields_ = [("supersteps", C.c_int64), ("nodes_donated", C.c_int64), ("nodes_adopted", C.c_int64),
+                ("candidates_sent", C.c_int64), ("candidates_received", C.c_int64), ("seconds_collectives", C.c_double)]
+
+
+def _bind_sharded(lib):
+    if getattr(lib, "_stcsp_sharded_bound", False):
+        return
+    lib.stcsp_engine_solve_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ShardedOptions), C.POINTER(ShardedStats)]
+    lib.stcsp_local_group_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    lib.stcsp_local_group_transport.argtypes = [C.c_void_p, C.c_int32]
+    lib.stcsp_local_group_transport.restype = C.c_void_p
+    lib.stcsp_local_group_destroy.argtypes = [C.c_void_p]
+    lib.stcsp_local_group_destroy.restype = None
+    lib._stcsp_sharded_bound = True
+
+
+def solve_sharded_native(engine: "Engine", transport: int, budget_rounds: int = 8, share_per_rank: int = 64) -> dict:
+    """stcsp_engine_solve_sharded: the whole superstep loop of this rank inside the engine library (no Python, no torch
+    between two bursts of k_expand); `transport` = pointer to a stcsp_transport (LocalGroup.transport(r), RcclTransport.ptr)."""
+    lib = hip_lib()
+    _bind_sharded(lib)
+    o = ShardedOptions(budget_rounds, share_per_rank, 0)
+    st = ShardedStats()
+    engine._check(lib.stcsp_engine_solve_sharded(engine._h, C.c_void_p(transport), C.byref(o), C.byref(st)))
+    return {n: getattr(st, n) for n, _ in st._fields_}
+
+
+class LocalGroup:
+    """stcsp_local_group: `world` transports for `world` engines of ONE process, one host thread each (same or different
+    GPUs; records move with hipMemcpy[Peer]Async)."""
+
+    def __init__(self, world: int):
+        lib = hip_lib()
+        _bind_sharded(lib)
+        self._lib, self.world = lib, world
+        h = C.c_void_p()
+        rc = lib.stcsp_local_group_create(world, C.byref(h))
+        if rc != 0:
+            raise StcspError(rc, "local group")
+        self._h = h
+
+    def transport(self, rank: int) -> int:
+        return self._lib.stcsp_local_group_transport(self._h, rank)
+
+    def solve(self, engines, **knobs):
+        """Run stcsp_engine_solve_sharded on every engine, one thread per rank; returns the per-rank stats (raises the
+        first rank's error after ALL threads have ended)."""
+        import threading
+        out, errs = [None] * self.world, [None] * self.world
+
+        def run(r):
+            try:
+                out[r] = solve_sharded_native(engines[r], self.transport(r), **knobs)
+            except Exception as ex:  # noqa: BLE001
+                errs[r] = ex
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        self.errors = errs
+        for ex in errs:
+            if ex is not None:
+                raise ex
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.stcsp_local_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_rccl = None
+
+
+def rccl_lib() -> C.CDLL:
+    """libstcsp_rccl.so: the stcsp_transport over RCCL (one process per GPU)."""
+    global _rccl
+    if _rccl is None:
+        path = CSRC / "libstcsp_rccl.so"
+        if not path.exists():
+            raise RuntimeError(f"{path} is missing -- build it (make -C {CSRC})")
+        lib = C.CDLL(str(path))
+        lib.stcsp_rccl_unique_id.argtypes = [C.c_void_p]
+        lib.stcsp_transport_rccl_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.stcsp_transport_rccl_destroy.argtypes = [C.c_void_p]
+        lib.stcsp_transport_rccl_destroy.restype = None
+        _rccl = lib
+    return _rccl
+
+
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    rc = rccl_lib().stcsp_rccl_unique_id(buf)
+    if rc != 0:
+        raise StcspError(rc, "ncclGetUniqueId failed")
+    return buf.raw
+
+
+class RcclTransport:
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        lib = rccl_lib()
+        h = C.c_void_p()
+        rc = lib.stcsp_transport_rccl_create(C.create_string_buffer(unique_id, RCCL_ID_BYTES), rank, world, device, C.byref(h))
+        if rc != 0:
+            raise StcspError(rc, "ncclCommInitRank failed")
+        self._lib, self.ptr = lib, h.value
+
+    def close(self):
+        if self.ptr:
+            self._lib.stcsp_transport_rccl_destroy(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
 def merge_shards(results):
     """stcsp_merge_shards over a list of Result structs; returns (handle, Result)."""
     lib = host_lib()

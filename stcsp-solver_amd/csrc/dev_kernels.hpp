@@ -254,7 +254,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         // sharded runs: a leaf whose successor state belongs to another shard becomes a candidate
         // record for its owner (header, signature, edge label, block); one that belongs to this
         // shard is committed right here like in an unsharded run
-        if (c.sharded && lo.owner != c.rank) {
+        if (c.sharded && (lo.owner != c.rank || c.sharded == 2)) {  // (2: tests send every leaf through the exchange, own ones too)
             uint32_t pos = 0;
             if (lane == 0) pos = atomicAdd(&c.ctl[L_.cand0 + (lo.owner * R + ro) * CST], 1u);
             pos = rflu(pos);
@@ -640,7 +640,7 @@ __global__ void k_close_segment(Ctx c) {
 #define STCSP_BIG_WAVES 16  // wavefronts of a big workgroup
 #endif
 template <int DR, bool L, bool CS, bool LITE, bool BIG = false, int W = 1>
-__global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : STCSP_WIDE_WAVES)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id) {
+__global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : STCSP_WIDE_WAVES)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id, uint32_t tab_gen) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     // the planned round's gate in ONE 8-byte read (Plan::gate): is it this launch's round, and how many slots has it? The plan
@@ -696,6 +696,13 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     uint32_t hot[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
+    {
+        // the state table's generation changes with every solve; the device copy of the context does not have to: the launch
+        // brings it along and it goes straight into the register copy the node loops read
+        constexpr int gw_ = (int)(offsetof(Ctx, tab_gen) / 4);
+        static_assert(gw_ < 64, "tab_gen sits in the first register of the context copy");
+        if (lane == gw_) hot[0] = tab_gen;
+    }
 #ifdef STCSP_STATIC_SLOTS
     for (int gw = blockIdx.x * wpb + wib; gw < n_slots; gw += total_waves) expand_node<DR, L, CS, LITE, W>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
 #else
@@ -815,7 +822,8 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
     out.ok = false;
     out.set = set;
     out.err = 0;
-    const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
+    const uint32_t gen = c.tab_gen;
+    const int esz = 1 << c.tab_shift;
     uint32_t pos = (uint32_t)h & c.slot_mask;
     uint32_t idx = 0;
     bool is_new = false;
@@ -823,20 +831,26 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
     uint32_t e = 0;
     if (lane == 0) e = atomicAdd(&c.ctl[L.edge0 + ro * CST], 1u);
     for (unsigned probes = 0;; probes++) {
+        uint32_t *ent = (uint32_t *)c.slots + ((size_t)pos << c.tab_shift);
+        unsigned long long *sw = (unsigned long long *)(ent + esz - 2);
+        // ONE round trip: the slot word and the key of the entry (same 128-byte line), the slot word requested first -- a
+        // publisher writes the key, drains its stores, then the index, so a reader that sees the index sees the key
         unsigned long long sv = 0;
-        bool claimed = false;
-        if (lane == 0) {
-            sv = __hip_atomic_load(&c.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sv == 0) {
-                unsigned long long want = ((unsigned long long)htag << 32) | kPending;
-                unsigned long long old = atomicCAS(&c.slots[pos], 0ull, want);
-                claimed = old == 0;
-                sv = old;
-            }
-        }
+        if (lane == 0) sv = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t other = 0;
+        if (lane < c.KL) other = __hip_atomic_load(&ent[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t lo = rflu((uint32_t)sv), hi = rflu((uint32_t)(sv >> 32));
-        if (__ballot(claimed)) {
-            // claimed: allocate the state, publish its key, then publish the index
+        if (hi != gen) {  // free (empty, or left over from an earlier solve): claim it
+            bool claimed = false;
+            if (lane == 0) claimed = atomicCAS(sw, sv, ((unsigned long long)gen << 32) | kPending) == sv;
+            if (!__ballot(claimed)) {  // somebody else was faster: look at the entry again
+                if (probes > c.slot_mask) {
+                    out.err = ERR_STATE_OVERFLOW;
+                    return out;
+                }
+                continue;
+            }
+            // claimed: allocate the state, publish its key (in the entry; and in state_keys for the export), then the index
             uint32_t ni = 0;
             if (lane == 0) ni = atomicAdd(&misc[MISC_NSTATES * CST], 1u);
             ni = rflu(ni);
@@ -844,36 +858,41 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
                 out.err = ERR_STATE_OVERFLOW;
                 return out;
             }
-            if (lane < c.KL) __hip_atomic_store(&c.state_keys[(size_t)ni * c.KL + lane], kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < c.KL) {
+                __hip_atomic_store(&ent[lane], kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c.state_keys[(size_t)ni * c.KL + lane] = kw;  // (read by later launches and the export kernels only)
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(&c.slots[pos], ((unsigned long long)htag << 32) | ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(sw, ((unsigned long long)gen << 32) | ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             STCSP_REJOIN();
             idx = ni;
             is_new = true;
             break;
         }
-        if (hi == htag) {
-            unsigned spins = 0;
-            while (lo == kPending) {  // another wavefront is publishing this slot
-                __builtin_amdgcn_s_sleep(2);
-                unsigned long long t = 0;
-                if (lane == 0) t = __hip_atomic_load(&c.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lo = rflu((uint32_t)t);
-                if (++spins > (1u << 22)) {
-                    out.err = ERR_TABLE_SPIN;
-                    return out;
-                }
+        unsigned spins = 0;
+        while (lo == kPending) {  // another wavefront is publishing this entry: read slot word and key again
+            __builtin_amdgcn_s_sleep(2);
+            unsigned long long t = 0;
+            if (lane == 0) t = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < c.KL) other = __hip_atomic_load(&ent[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = rflu((uint32_t)t);
+            if (++spins > (1u << 22)) {
+                out.err = ERR_TABLE_SPIN;
+                return out;
             }
-            // no acquire fence: every access to a key word is an agent-scope (sc1, L1-bypassing)
-            // atomic, the publisher drained its stores before the index became visible
-            uint32_t other = 0;
-            if (lane < c.KL) other = __hip_atomic_load(&c.state_keys[(size_t)lo * c.KL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!__ballot(lane < c.KL && other != kw)) {
-                idx = lo;
-                break;
-            }
+        }
+        if (!__ballot(lane < c.KL && other != kw)) {
+            idx = lo;
+            break;
+        }
+        // another state's entry. (Belt and braces: a key that differs is read once more before the probe moves on -- a
+        // duplicate state would be a wrong automaton, a second read of a colliding entry costs a round trip on a path that
+        // tables at most half full rarely take.)
+        if (lane < c.KL) other = __hip_atomic_load(&ent[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__ballot(lane < c.KL && other != kw)) {
+            idx = lo;
+            break;
         }
         pos = (pos + 1) & c.slot_mask;
         if (probes > c.slot_mask) {
@@ -1145,11 +1164,19 @@ __global__ __launch_bounds__(256) void k_tabulate(TabArgs a, uint32_t *bitmap) {
 __global__ void k_rehash(Ctx c, uint32_t n_states) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
-    const unsigned long long h = key_hash(c.state_keys + (size_t)i * c.KL, c.KL);
-    const uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
+    const uint32_t *key = c.state_keys + (size_t)i * c.KL;
+    const unsigned long long h = key_hash(key, c.KL);
+    const int esz = 1 << c.tab_shift;
     uint32_t pos = (uint32_t)h & c.slot_mask;
-    const unsigned long long want = ((unsigned long long)htag << 32) | i;
-    while (atomicCAS(&c.slots[pos], 0ull, want) != 0ull) pos = (pos + 1) & c.slot_mask;
+    const unsigned long long want = ((unsigned long long)c.tab_gen << 32) | i;
+    for (;;) {  // (the new table is zeroed: generation 0 is never a solve's)
+        uint32_t *ent = (uint32_t *)c.slots + ((size_t)pos << c.tab_shift);
+        if (atomicCAS((unsigned long long *)(ent + esz - 2), 0ull, want) == 0ull) {
+            for (int j = 0; j < c.KL; j++) ent[j] = key[j];
+            return;
+        }
+        pos = (pos + 1) & c.slot_mask;
+    }
 }
 
 // ------------------------------------------------------------------ export (unsharded runs)

@@ -130,6 +130,13 @@ struct Ctx {
     int *miss;
     int miss_cap;
     int max_iw;  // widest dirty mask (words) over the program's constraint sets
+    // State table = `slot_mask + 1` ENTRIES of 2^tab_shift words (one or more whole 128-byte lines): the state's key
+    // [set tag, signature...] in words [0, KL) and the slot word {hi: generation of the solve that wrote it, lo: state index or
+    // kPending} in the last two -- "is this the state I am looking for?" is decided by ONE line read (round 3: slot word, then
+    // the key out of state_keys: two dependent round trips at every leaf). An entry whose generation is not the running
+    // solve's is free: no memset of the table between solves.
+    int tab_shift;
+    uint32_t tab_gen;
     // ---- beyond word 63: general wavefront revisions and diagnostics only
     int budget_bitmap, budget_code;  // odometer steps one wavefront revision may take (bitmap lookup / bytecode); longer ones are skipped
     int sib_depth;                   // node records on a wavefront's sibling stack (kSibDepth; 2 under the big-workgroup variant)
@@ -141,6 +148,7 @@ struct Ctx {
     Progress *progress;  // null: no mirror
 };
 static_assert(offsetof(Ctx, budget_bitmap) <= 64 * 4, "the node loops' part of Ctx must fit one lane-striped register");
+__host__ __device__ inline int table_entry_shift(int KL) { return KL <= 30 ? 5 : (KL <= 62 ? 6 : 7); }  // 32 / 64 / 128 words per entry
 
 struct ExpandArgs {  // per-round view, read from the device plan by every wavefront
     const uint32_t *in_base;

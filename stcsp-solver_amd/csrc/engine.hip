@@ -130,6 +130,7 @@ struct stcsp_engine {
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
     int64_t step_max_rounds = 0, step_min_open = 0;  // expand_local budget (set_expand_budget): 0 = run the frontier dry
     DevBuf<uint32_t> d_xfer;                          // donated open nodes (transfer records)
+    DevBuf<uint32_t> d_recv_cand, d_recv_nodes;       // stcsp_engine_solve_sharded: candidate / transfer records received from the peers
     std::vector<DevSegment> h_stack;
     std::vector<uint32_t *> pack_ptr;
     std::vector<int64_t> pack_count;
@@ -490,6 +491,14 @@ struct stcsp_engine {
         if (opt.world <= 0) opt.world = 1;
         if (opt.rank < 0 || opt.rank >= opt.world) return fail(STCSP_E_INVALID, "rank %d outside world %d", opt.rank, opt.world);
         sharded = opt.world > 1 || (opt.flags & STCSP_F_STEPPED) != 0;
+        if (const char *ev = getenv("STCSP_FAULT")) {
+            std::string f(ev);
+            const size_t c1 = f.find(','), c2 = c1 == std::string::npos ? c1 : f.find(',', c1 + 1);
+            if (c1 != std::string::npos && atoi(f.c_str() + c1 + 1) == opt.rank) {
+                fault_call = f.substr(0, c1);
+                fault_left = c2 == std::string::npos ? 1 : std::max(1, atoi(f.c_str() + c2 + 1));
+            }
+        }
         int rc = mgr.init(p, sharded);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
         mgr.device_tabulation = !(getenv("STCSP_DEVICE_TABULATE") && atoi(getenv("STCSP_DEVICE_TABULATE")) == 0);
@@ -543,6 +552,9 @@ struct stcsp_engine {
         ctx.ES = edge_stride(N);
         ctx.world = opt.world;
         ctx.sharded = sharded ? 1 : 0;
+        // tests: every leaf becomes a candidate record, also those this shard owns -- so that a group of ONE rank still moves
+        // records through its transport (RCCL send / recv to itself) and through k_commit
+        if (sharded && getenv("STCSP_FORCE_CANDIDATES") && atoi(getenv("STCSP_FORCE_CANDIDATES")) != 0) ctx.sharded = 2;
         ctx.budget_bitmap = (int)kBudgetBitmapIters;
         ctx.budget_code = (int)kBudgetCodeIters;
         if (const char *ev = getenv("STCSP_BUDGET_BITMAP")) ctx.budget_bitmap = std::max(1, atoi(ev));
@@ -647,8 +659,12 @@ struct stcsp_engine {
     }
 
     int alloc_table(uint32_t slots) {
-        HIPCHK(d_slots.alloc(slots));
-        HIPCHK(hipMemsetAsync(d_slots.p, 0, (size_t)slots * sizeof(unsigned long long), stream));
+        // entries of 2^tab_shift words (key + slot word in one or more whole 128-byte lines: dev_layout.hpp Ctx::tab_shift);
+        // zeroed here, never again: an entry belongs to the solve whose generation it carries
+        ctx.tab_shift = table_entry_shift(ctx.KL);
+        const size_t u64s = ((size_t)slots << ctx.tab_shift) / 2;
+        HIPCHK(d_slots.alloc(u64s));
+        HIPCHK(hipMemsetAsync(d_slots.p, 0, u64s * sizeof(unsigned long long), stream));
         ctx.slots = d_slots.p;
         ctx.slot_mask = slots - 1;
         return STCSP_OK;
@@ -698,6 +714,7 @@ struct stcsp_engine {
     }
     int flush_ctx() {
         sync_ctx();
+        h_ctx->tab_gen = ctx.tab_gen;  // (travels with every launch: no reason to refresh the device copy)
         if (memcmp(h_ctx, &ctx, sizeof(Ctx)) != 0) {  // pools / program moved: refresh the device copy
             HIPCHK(hipStreamSynchronize(stream));      // (the staging copy may still be in flight)
             memcpy(h_ctx, &ctx, sizeof(Ctx));
@@ -867,7 +884,10 @@ struct stcsp_engine {
         HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));
         for (int i = 0; i < L.words; i++) h_ctl[i] = 0;
         HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
-        HIPCHK(hipMemsetAsync(d_slots.p, 0, ((size_t)ctx.slot_mask + 1) * sizeof(unsigned long long), stream));
+        if (++ctx.tab_gen == 0u) {  // (2^32 solves on one engine: start over with a clean table)
+            HIPCHK(hipMemsetAsync(d_slots.p, 0, d_slots.n * sizeof(unsigned long long), stream));
+            ctx.tab_gen = 1u;
+        }
         memset(h_plan, 0, sizeof(Plan));
         chunk_r = chunk_r0;
         h_plan->chunk_r = chunk_r;
@@ -882,22 +902,23 @@ struct stcsp_engine {
             // With an empty signature a leaf of set 0 must find it again, so the key is the plain
             // (tag 0); otherwise a reserved tag keeps it apart from a state with an all-zero signature.
             // (staged in pinned memory: small copies from pageable memory block the host for ~10 us each)
-            const size_t stage_words = (size_t)ctx.KL + 4 + ctx.NS;
+            const size_t esz = (size_t)1 << ctx.tab_shift;
+            const size_t stage_words = esz + 4 + ctx.NS;
             if (h_begin_words < stage_words) {
                 if (h_begin) (void)hipHostFree(h_begin);
                 HIPCHK(hipHostMalloc((void **)&h_begin, stage_words * sizeof(uint32_t)));
                 h_begin_words = stage_words;
             }
-            uint32_t *key = h_begin, *slotw = h_begin + ctx.KL, *one = slotw + 2, *node = one + 2;
-            for (int i = 0; i < ctx.KL; i++) key[i] = 0u;
+            // the root's table entry: [key ... | slot word {generation, state 0}]
+            uint32_t *key = h_begin, *slotw = h_begin + esz - 2, *one = h_begin + esz, *node = one + 4;
+            for (size_t i = 0; i < esz; i++) key[i] = 0u;
             key[0] = ctx.sig_len == 0 ? 0u : kRootTag;
             const unsigned long long h = key_hash(key, ctx.KL);
-            uint32_t htag = (uint32_t)(h >> 32) | 0x80000000u;
-            unsigned long long slot = ((unsigned long long)htag << 32) | 0u;
+            unsigned long long slot = ((unsigned long long)ctx.tab_gen << 32) | 0u;
             memcpy(slotw, &slot, sizeof slot);
             one[0] = 1u;
             HIPCHK(hipMemcpyAsync(d_state_keys.p, key, ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_slots.p + ((uint32_t)h & ctx.slot_mask), slotw, sizeof slot, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync((uint32_t *)d_slots.p + ((size_t)((uint32_t)h & ctx.slot_mask) << ctx.tab_shift), key, esz * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NSTATES * CST, one, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             n_states = 1;
             // root search node: initial domains at every point (variable.cpp:24-29), set 0
@@ -986,21 +1007,21 @@ struct stcsp_engine {
     void launch_expand() {
         const Ctx *cp = (const Ctx *)d_ctx.p;
         if (mgr.W == 2) {
-            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 2>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 2>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
             return;
         }
         if (mgr.W > 2) {
-            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 4>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+            hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 4>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
             return;
         }
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
             if constexpr ((V & 5) == 5)
                 if (big) {
-                    hipLaunchKernelGGL((k_expand<DRT, true, (V & 2) != 0, true, true>), dim3(max_blocks), dim3(STCSP_BIG_WAVES * 64), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+                    hipLaunchKernelGGL((k_expand<DRT, true, (V & 2) != 0, true, true>), dim3(max_blocks), dim3(STCSP_BIG_WAVES * 64), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
                     return;
                 }
-            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++);
+            hipLaunchKernelGGL((k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
         });
     }
 
@@ -1456,9 +1477,18 @@ struct stcsp_engine {
         return read_counters(snap);
     }
 
+    // tests: STCSP_FAULT="<call>,<rank>[,<nth>]" makes the nth invocation (default 1st) of one stepping call fail on one
+    // rank -- what the failure protocol of the sharded drivers is tested with (no rank may be left waiting in a collective)
+    std::string fault_call;
+    int fault_left = 0;
+    bool fault_hit(const char *call) {
+        if (fault_call != call || fault_left <= 0) return false;
+        return --fault_left == 0;
+    }
     // ---- sharded stepping
     int expand_local(int64_t *left) {
         if (!begun) return fail(STCSP_E_STATE, "expand_local before begin");
+        if (fault_hit("expand_local")) return fail(STCSP_E_INTERNAL, "injected fault in expand_local");
         packed = false;
         const auto t0 = std::chrono::steady_clock::now();
         int rc = run_rounds();
@@ -1507,6 +1537,7 @@ struct stcsp_engine {
     }
     int commit(const void *records, int64_t count) {
         if (!begun) return fail(STCSP_E_STATE, "commit before begin");
+        if (fault_hit("commit")) return fail(STCSP_E_INTERNAL, "injected fault in commit");
         tail_fresh = false;
         // the outbox has been handed over: empty it
         packed = false;
@@ -1560,6 +1591,7 @@ struct stcsp_engine {
     // ---- frontier redistribution (stcsp_engine.h): the oldest open nodes leave / received ones join
     int donate(int64_t want, void **ptr, int64_t *count) {
         if (!begun || !sharded) return fail(STCSP_E_STATE, "donate is part of the sharded stepping interface (after begin)");
+        if (fault_hit("donate")) return fail(STCSP_E_INTERNAL, "injected fault in donate");
         tail_fresh = false;
         *ptr = nullptr;
         *count = 0;
@@ -1608,6 +1640,7 @@ struct stcsp_engine {
     }
     int adopt(const void *records, int64_t count) {
         if (!begun || !sharded) return fail(STCSP_E_STATE, "adopt is part of the sharded stepping interface (after begin)");
+        if (fault_hit("adopt")) return fail(STCSP_E_INTERNAL, "injected fault in adopt");
         tail_fresh = false;
         if (count <= 0) return STCSP_OK;
         int rc = STCSP_OK;
@@ -1636,6 +1669,9 @@ struct stcsp_engine {
         const size_t E = exp_edges;
         const uint32_t S = n_states;
         auto width = [&](int v) { return mgr.ub[v] - mgr.lb[v] + 1; };
+        for (int v : {a1, op, ava})
+            if (v >= 0 && width(v) > 32)
+                return fail(STCSP_E_UNSUPPORTED, "device adversarial passes keep one 32-bit cover word per state: variable %d has %d values (use the host passes of stcsp_host.h)", v, width(v));
         auto full_mask = [&](int v) { return width(v) >= 32 ? 0xffffffffu : ((1u << width(v)) - 1u); };
         const int wa = op >= 0 ? width(ava) : 0;
         if (d_pvalid.n < S) {
@@ -2158,3 +2194,10 @@ int stcsp_engine_sets_import(stcsp_engine *e, const int32_t *words, int64_t n) {
 }
 
 }  // extern "C"
+
+#define HIPCHK_E(e, call)                                                                                         \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess) return (e)->fail(STCSP_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#include "sharded_native.hpp"

@@ -93,3 +93,19 @@ def test_fuzz_wide_domains(stcsp, RefOracle, block):
         nontrivial += a.n_live_states > 3
         e.close()
     assert checked >= 80 and w4 >= 20 and nontrivial >= 10
+
+
+@pytest.mark.parametrize("name", ["hull_next_sum", "neg_w4"])
+def test_wide_models_two_hip_shards_one_gpu(stcsp, RefOracle, tmp_path, name):
+    """Chunked blocks through the sharded pipeline (candidate records, commit, frontier redistribution) with two
+    HIP-engine shards on one GPU."""
+    from test_sharded import launch, SHARE
+    f = tmp_path / f"{name}.csp"
+    f.write_text(WIDE[name])
+    m = stcsp.Model(text=WIDE[name])
+    o = RefOracle(m)
+    ro = o.solve()
+    ao, _ = finish(o, ro)
+    r = launch(2, f"file:{f}", "hip", tmp_path, env=SHARE)
+    assert r["sha"] == ao.canonical_sha256() and r["dom"] == ro.counters.dominance
+    assert sum(r["donated"]) == sum(r["adopted"])

@@ -16,7 +16,7 @@ src = CSRC / "engine.hip"
 if one:
     src = Path("/tmp/engine_one.hip")
     src.write_text('#include <hip/hip_runtime.h>\n#include <climits>\n#include "device_types.hpp"\n#include "stcsp_engine.h"\nusing namespace stcsp;\n'
-                   f'#include "dev_kernels.hpp"\ntemplate __global__ void stcsp::dev::k_expand<{one}>(const stcsp::dev::Ctx *, const stcsp::dev::Plan *, unsigned);\n')
+                   f'#include "dev_kernels.hpp"\ntemplate __global__ void stcsp::dev::k_expand<{one}>(const stcsp::dev::Ctx *, const stcsp::dev::Plan *, unsigned, uint32_t);\n')
 cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", f"-I{CSRC.parent.parent / 'include'}",
        f"-I{CSRC}", "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", "/tmp/engine_res.o"] + extra
 if "-save-temps" in extra:
