@@ -257,7 +257,7 @@ def make_engine_factory(st, local_rank):
     return lambda model, **kw: st.Engine(model, device=local_rank, **kw)
 
 
-def sharded_workload(st, sh, dist, torch, make_engine, model, rank, world, dev, label, time_limit_s=0.0, repeats=2, expect=None, knobs=None):
+def sharded_workload(st, sh, dist, torch, make_engine, model, rank, world, dev, label, time_limit_s=0.0, repeats=2, expect=None, knobs=None, run=None):
     """One workload through solve_sharded on all ranks (N>1 line): whole-job nodes/s with per-rank search nodes,
     donated / adopted open nodes, supersteps and the wall time spent in collectives."""
     eng = make_engine(model, rank=rank, world=world, time_limit_s=time_limit_s,
@@ -267,7 +267,10 @@ def sharded_workload(st, sh, dist, torch, make_engine, model, rank, world, dev, 
         stats = {}
         dist.barrier()
         t0 = time.perf_counter()
-        sh.solve_sharded(eng, rank, world, dev, stats=stats, **(knobs or {}))
+        if run is not None:
+            run(eng, stats)  # the native loop (stcsp_engine_solve_sharded)
+        else:
+            sh.solve_sharded(eng, rank, world, dev, stats=stats, **(knobs or {}))
         if dev.type == "cuda":
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -310,6 +313,9 @@ def main():
                     help="N>1 (and --stepped) only: a second, larger instance through the sharded pipeline, outside the timed region")
     ap.add_argument("--budget-rounds", type=int, default=8, help="sharded runs: launch rounds per superstep once a rank holds enough open nodes to share")
     ap.add_argument("--share-per-rank", type=int, default=64, help="sharded runs: ... 'enough' = this many open nodes per rank")
+    ap.add_argument("--python-driver", action="store_true",
+                    help="sharded runs: drive the supersteps from stcsp-solver_amd/sharded.py over torch.distributed instead of the "
+                         "native loop (stcsp_engine_solve_sharded over the RCCL transport of libstcsp_rccl.so)")
     ap.add_argument("--stepped", action="store_true",
                     help="N=1 only: run the sharded pipeline (size-1 RCCL group, STCSP_F_STEPPED) -- the N>1 code path on one GPU")
     args = ap.parse_args()
@@ -360,13 +366,30 @@ def main():
     sh = importlib.import_module("stcsp-solver_amd.sharded") if stepped else None
     sstats = {}
     knobs = dict(budget_rounds=args.budget_rounds, share_per_rank=args.share_per_rank)
+    # Sharded runs of the HIP engine: the superstep loop runs INSIDE the engine library (include/stcsp_sharded.h) over the RCCL
+    # transport -- one more communicator next to torch's, its unique id broadcast through the process group; torch.distributed
+    # is left with the barriers around the timed region and the final gather. (--python-driver: the loop of sharded.py.)
+    native = stepped and not cpu_test and not args.python_driver
+    transport = None
+    if native:
+        uid = torch.zeros(st.RCCL_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(st.rccl_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(uid, 0)
+        transport = st.RcclTransport(bytes(uid.cpu().tolist()), rank, world, local_rank)
+
+    def run_native(engine, stats):
+        stats.update(st.solve_sharded_native(engine, transport.ptr, **knobs))
 
     def one_step():
         """One full solve: search + ok-fixpoint + compaction + copy to the host (per shard when sharded)."""
         if not stepped:
             res = eng.solve()
             return res.counters, res
-        sh.solve_sharded(eng, rank, world, dev, stats=sstats, **knobs)
+        if native:
+            run_native(eng, sstats)
+        else:
+            sh.solve_sharded(eng, rank, world, dev, stats=sstats, **knobs)
         res = eng.export()  # this shard's states and raw edges on the host (the merge on rank 0 is outside the step)
         return eng.counters(), res
 
@@ -463,13 +486,13 @@ def main():
             if args.scalable_workload:
                 exp = {"partialorder_16": 6112188, "partialorder_18": 27678644}.get(args.scalable_workload)
                 scalable[args.scalable_workload] = sharded_workload(st, sh, dist, torch, make_engine, st.Model.from_name(args.scalable_workload), rank, world,
-                                                                    dev, args.scalable_workload, repeats=2, expect=exp, knobs=knobs)
+                                                                    dev, args.scalable_workload, repeats=2, expect=exp, knobs=knobs, run=run_native if native else None)
             if args.synthetic_seconds > 0:
                 n, d, mp, s_, seed = SYNTH_SHAPE
                 scalable["synthetic_64x32" if SYNTH_SHAPE == SYNTH else "synthetic"] = sharded_workload(st, sh, dist, torch, make_engine, synthetic_model(st), rank, world, dev,
                                                                f"synthetic {n} vars x |D|={d}, {mp} + {s_} constraints, seed {seed}",
-                                                               time_limit_s=args.synthetic_seconds, repeats=2, knobs=knobs)
-        except sh.ShardedSolveError as ex:  # agreed on every rank
+                                                               time_limit_s=args.synthetic_seconds, repeats=2, knobs=knobs, run=run_native if native else None)
+        except (sh.ShardedSolveError, st.StcspError) as ex:  # agreed on every rank (python driver / native loop)
             scalable["error"] = f"{type(ex).__name__}: {ex}"
         # a scalable workload that failed, or expanded another number of nodes than the unsharded search does, fails the run
         if "error" in scalable or any(isinstance(v, dict) and v.get("nodes_ok") is False for v in scalable.values()):
@@ -504,6 +527,11 @@ def main():
                "per_node": {"item_revisions": revs / max(nodes, 1) * (world if stepped else 1), "tuple_evaluations": evals / max(nodes, 1) * (world if stepped else 1),
                             "wavefront_revisions": wrevs / max(nodes, 1) * (world if stepped else 1), "sweeps": sweeps / max(nodes, 1) * (world if stepped else 1)},
                "sharding": "none" if not stepped else f"state-owner x{world}"}
+        if stepped:
+            cfg["superstep_driver"] = ("native: stcsp_engine_solve_sharded over the RCCL transport (libstcsp_rccl.so: ncclAllGather for the count table, "
+                                       "grouped ncclSend / ncclRecv on the engine's stream)" if native else "python: stcsp-solver_amd/sharded.py over torch.distributed")
+            if world > 1:
+                cfg["multi_gpu_note"] = "the builder's pool has one GPU per box: every N > 1 figure comes from the driver's run, none was measured while building"
         if cpu_test:
             cfg["engine"] = HOOKS["label"] or "TEST ONLY: injected stand-in engine (not a measurement of the product)"
         if stepped:
@@ -528,6 +556,18 @@ def main():
             except Exception as ex:
                 others["synthetic_64x32"] = {"error": f"{type(ex).__name__}: {ex}"}
             cfg["other_workloads"] = others
+            # the same workload from a process WITHOUT PyTorch's HIP runtime (the runtime a C++ host linked against /opt/rocm
+            # gets: INTEGRATION.md's binding, the stcsp CLI); outside the timed region, this process idle meanwhile
+            try:
+                import subprocess
+                r_ = subprocess.run([sys.executable, str(REPO / "tools" / "bench_no_torch.py"), args.workload, str(args.steps), str(min(args.warmup, 5))],
+                                    capture_output=True, text=True, timeout=300)
+                line = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
+                cfg["without_pytorch_runtime"] = json.loads(line[-1]) if line else {"error": (r_.stderr or r_.stdout)[-400:]}
+                if line and not cfg["without_pytorch_runtime"].get("parity_ok", False) and args.workload in golden:
+                    parity_ok = False
+            except Exception as ex:  # noqa: BLE001 -- the headline line must survive
+                cfg["without_pytorch_runtime"] = {"error": f"{type(ex).__name__}: {ex}"}
         out = {
             "metric": f"search-tree nodes/sec on {args.workload}.csp",
             "value": nodes / elapsed,

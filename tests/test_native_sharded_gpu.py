@@ -103,3 +103,26 @@ def test_native_sharded_rccl_world1(stcsp, golden, monkeypatch, name):
     assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (gold["states"], gold["edges"], gold["canonical_sha256"])
     assert st["candidates_sent"] == st["candidates_received"] == e.counters().leaves > 0  # every leaf travelled
     t.close()
+
+
+@pytest.mark.parametrize("name,flags", [("juggling_b4_f6", ["-s"]), ("digitinvader4", ["-s", "-a"]), ("partialorder_11", ["-s"])])
+def test_cli_shards_writes_the_same_files(stcsp, tmp_path, name, flags):
+    """`stcsp --shards=N` (N host threads, one engine each, in-process transport) against the unsharded command line: the
+    same statistics fields and byte-identical solutions.dot (the writer orders edges by label)."""
+    import subprocess
+    exe = stcsp.CSRC / "stcsp"
+    src = tmp_path / f"{name}.csp"
+    src.write_text(stcsp.instances.by_name(name))
+    outs = []
+    for extra in ([], ["--shards=2"], ["--shards=3"]):
+        d = tmp_path / ("one" if not extra else extra[0].replace("=", ""))
+        d.mkdir()
+        r = subprocess.run([str(exe), *flags, *extra, str(src)], cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        line = r.stdout.strip().split("\n")[-1]
+        head = r.stdout[: r.stdout.rfind(line)]
+        fields = line.split("\t")
+        outs.append((head, fields[1:6], (d / "solutions.dot").read_bytes()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]          # "adver1: ..." part
+    assert outs[0][1][:3] == outs[1][1][:3] == outs[2][1][:3]  # var con dom
+    assert outs[0][2] == outs[1][2] == outs[2][2]
