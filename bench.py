@@ -95,13 +95,26 @@ def launch_ranks(args, argv):
 
 
 def host_cpu_share():
-    """CPUs this process may run on (the affinity mask: a GPU box hands a job a share of its host cores), and the number of
-    workers the all-cores legs use: the share, capped at 64 (the restatement's shared state table stops scaling there)."""
+    """(CPUs this process may run on, workers for the all-cores CPU legs, where that number comes from).  A GPU box hands a
+    one-GPU job a SHARE of its host cores: the affinity mask (os.sched_getaffinity) or the cgroup's CPU quota (cpu.max) say
+    so when the box enforces it; this pool enforces it with neither (round 4: the mask showed all 256 CPUs and 64 workers ran
+    3.7x SLOWER than 16 -- the cores are shared with the other tenants), its documented share is 16 cores per GPU, which is
+    therefore the cap."""
     try:
-        share = len(os.sched_getaffinity(0))
+        mask = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        share = os.cpu_count() or 1
-    return share, max(1, min(share, 64))
+        mask = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    share = min(mask, quota) if quota else mask
+    workers = max(1, min(share, 16))
+    why = (f"affinity mask {mask} CPUs, cgroup quota {quota if quota else 'none'}; capped at the pool's documented share of 16 host cores per GPU")
+    return share, workers, why
 
 
 def cpu_baseline(st, name, seconds, threads):
@@ -129,7 +142,7 @@ def cpu_baseline(st, name, seconds, threads):
                      f"{'truncated' if r.truncated else 'complete'}); oracle/ref_dfs.cpp, 1 thread. The reference itself "
                      f"(unbuildable on this box) measured {REFERENCE_P14_NODES_PER_S:.0f} nodes/s on partialorder_14 on the "
                      "survey VM (1 core; it leaks 16 kB per leaf, half of its time is page faults)",
-           "host_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": host_cpu_share()[0]}
+           "host_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": host_cpu_share()[0], "all_cores_workers_from": host_cpu_share()[2]}
     if threads > 1:
         op = Ref(m, time_limit_s=seconds)
         t0 = time.time()
@@ -304,7 +317,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU legs (default: the CPUs in this process's affinity mask, os.sched_getaffinity, at most 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="workers of the all-cores CPU legs (default: min(affinity mask, cgroup CPU quota, 16 = the pool's share per GPU))")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--synthetic-seconds", type=float, default=2.0)
     ap.add_argument("--synthetic-cpu-seconds", type=float, default=5.0)

@@ -593,8 +593,19 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
     }
 }
 
+// the planner's verdict for the host (Progress::status / rounds / open_total): by the lane that wrote the plan words, after them
+__device__ __forceinline__ void mirror_plan(const Ctx &c, const Plan *p, int lane) {
+    if (c.progress && lane == 0) {
+        __hip_atomic_store(&c.progress->rounds, p->rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->open_total, p->open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->status, p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 __global__ void k_replan(Ctx c, unsigned next_launch) {
-    if (blockIdx.x == 0 && threadIdx.x < 64) plan_next(c, c.plan, threadIdx.x, next_launch);
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        plan_next(c, c.plan, threadIdx.x, next_launch);
+        mirror_plan(c, c.plan, threadIdx.x);
+    }
 }
 // sharded commit: open an output segment of `cap` slots per region / close it again
 __global__ void k_open_segment(Ctx c, unsigned cap) {
@@ -748,6 +759,7 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
             const unsigned long long t_k2 = PHASE_NOW();
             (void)t_k2;
             finalize_round(c, c.plan, lane, launch_id + 1u);
+            mirror_plan(c, c.plan, lane);
 #ifdef STCSP_PHASES
             if (lane == 0) {
                 add_stats(c, 0, ST_CYC_FINAL, PHASE_NOW() - t_k2);

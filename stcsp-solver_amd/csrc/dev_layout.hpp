@@ -98,6 +98,13 @@ struct Progress {
     // other, so the round before it has ENDED -- its snapshot may be shipped now, a whole round earlier than when the next
     // snapshot shows up
     unsigned long long started;
+    // What the host needs to decide about the next burst, written by whoever planned last (finalize_round of the last round run,
+    // or k_replan): read AFTER the burst's end has been seen (event), so no tags -- and no device-to-host copy of the plan, the
+    // control block and the statistics between two bursts (three small asynchronous copies cost ~50-80 us of every burst
+    // boundary under the ROCm 7.2 runtime, where bursts are short: engine.hip create()).
+    long long rounds, open_total;
+    int status;  // PlanStatus
+    int pad;
 };
 
 struct ImgOff {

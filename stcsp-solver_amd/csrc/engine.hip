@@ -628,15 +628,11 @@ struct stcsp_engine {
         HIPCHK(hipHostMalloc((void **)&h_ctx, sizeof(Ctx)));
         HIPCHK(hipHostMalloc((void **)&h_plan, sizeof(Plan)));
         if (!sharded && !(opt.time_limit_s > 0) && !(opt.max_search_nodes > 0)) burst = 32;  // (budgets are checked between bursts)
-        {
-            // HIP runtimes from 7.2 on start the export's asynchronous device-to-host copies only when the search stream's queued
-            // launches have drained (measured with /opt/rocm 7.2's libamdhip64: all of the export's copies ran AFTER the search,
-            // 2.1 ms per partialorder_14 solve instead of 0.26; the 7.0 runtime that PyTorch loads runs them beside it). Short
-            // bursts bound that wait: partialorder_14 solve + export 5.2 -> 4.0 ms there (3.35 with the 7.0 runtime).
-            int rtv = 0;
-            if (burst > 4 && !(opt.flags & STCSP_F_NO_EXPORT) && hipRuntimeGetVersion(&rtv) == hipSuccess && rtv >= 70200000) burst = 4;
-            if (getenv("STCSP_DEBUG")) fprintf(stderr, "[engine] HIP runtime %d, %d launches per burst\n", rtv, burst);
-        }
+        // (Round 3 enqueued bursts of 4 under HIP runtimes from 7.2 on: there the export streams' device-to-host copies only started
+        // when the search stream had drained. What held them back were read_plan's own three small copies, queued on the search
+        // stream behind the burst: the copy engine serves its requests in order, whatever stream they come from. With the planner's
+        // verdict in the pinned mirror (read_plan_fast) no copy waits behind a burst any more and both runtimes run bursts of 32:
+        // partialorder_14 under 7.2, solve + export: 3.99 -> 3.3 ms.)
         if (const char *ev = getenv("STCSP_BURST")) burst = std::max(1, atoi(ev));
         if (const char *ev = getenv("STCSP_CHAIN_SMALL")) {
             chain_small = std::max(1, atoi(ev));
@@ -771,7 +767,52 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     bool tail_fresh = false;  // h_ctl / h_stats hold the state after the last device work of the search (read_plan copied them)
-    int read_plan() {
+    // End of a burst. Fast path (the common case: the planner says "go on"): wait for the burst's end -- shipping finished parts
+    // of the edge log meanwhile -- and take the planner's verdict from the pinned mirror the device wrote it to; no copies.
+    // Anything else (done, a pool to grow, a translation, an error, a budget) takes the full read below.
+    bool mirror_ok = true;  // STCSP_PLAN_MIRROR=0: always copy (A/B)
+    int read_plan_fast(bool &handled) {
+        handled = false;
+        if (!ctx.progress || !mirror_ok) return STCSP_OK;
+        HIPCHK(hipEventRecord(ev_plan, stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev_plan);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIPCHK(q);
+            if (streaming) {
+                int rc = ship_progress();
+                if (rc != STCSP_OK) {
+                    (void)hipStreamSynchronize(stream);
+                    return rc;
+                }
+            }
+            std::this_thread::yield();
+        }
+        const volatile Progress *pr = h_progress;
+        if (pr->status != PS_RUN) return STCSP_OK;  // (the caller reads everything)
+        h_plan->status = PS_RUN;
+        h_plan->rounds = pr->rounds;
+        h_plan->open_total = pr->open_total;
+        for (int r = 0; r < R; r++) h_plan->edge_seen[r] = (unsigned)pr->edge_seen[r];
+        h_plan->states_seen = (unsigned)pr->states_seen;
+        levels = h_plan->rounds;
+        prog_have = false;
+        tail_fresh = false;
+        handled = true;
+        return STCSP_OK;
+    }
+    bool last_plan_fast = false;  // h_plan holds only what read_plan_fast fills in (status, rounds, open nodes, export cursors)
+    int read_plan(bool allow_fast = false) {
+        last_plan_fast = false;
+        if (allow_fast) {
+            bool handled = false;
+            int rc = read_plan_fast(handled);
+            if (rc != STCSP_OK) return rc;
+            if (handled) {
+                last_plan_fast = true;
+                return STCSP_OK;
+            }
+        }
         HIPCHK(hipMemcpyAsync(h_plan, d_plan.p, kPlanHeader, hipMemcpyDeviceToHost, stream));
         // ... and, behind it, what finish() reads when this burst turns out to be the last one: the control block and the
         // statistics (a few KB; a separate copy + synchronisation at the end costs ~40 us of every solve)
@@ -874,7 +915,9 @@ struct stcsp_engine {
         memset(h_progress, 0, sizeof(Progress));
         prog_have = false;
         prog_gen = 0;
-        ctx.progress = (streaming && !(getenv("STCSP_STREAM_POLL") && atoi(getenv("STCSP_STREAM_POLL")) == 0)) ? h_progress : nullptr;
+        // the progress mirror: edge-log cursors for the streaming export AND the planner's verdict for the host (read_plan_fast)
+        ctx.progress = !(getenv("STCSP_STREAM_POLL") && atoi(getenv("STCSP_STREAM_POLL")) == 0) ? h_progress : nullptr;
+        mirror_ok = !(getenv("STCSP_PLAN_MIRROR") && atoi(getenv("STCSP_PLAN_MIRROR")) == 0);
         translation_stops = 0;
         finished = false;
         exp_on_device = false;
@@ -1282,7 +1325,7 @@ struct stcsp_engine {
             if (prof) HIPCHK(hipEventRecord(ev_pool[ev_used++].second, stream));
             // the device is busy with the burst just enqueued: now is the time to ship the edges of the previous ones
             if (have_seen && ((rc = stream_edges(seen, false)) || (streaming && (rc = stream_states(seen_states))))) return rc;
-            rc = read_plan();
+            rc = read_plan(true);
             if (rc != STCSP_OK) return rc;
             for (int r = 0; r < R; r++) seen[r] = h_plan->edge_seen[r];
             seen_states = h_plan->states_seen;
@@ -1333,11 +1376,11 @@ struct stcsp_engine {
             }
             if (over_budget()) {
                 truncated = true;
-                return STCSP_OK;
+                return last_plan_fast ? read_plan(false) : STCSP_OK;
             }
             // sharded stepping with a budget: hand control back while there is still work to share
             if (sharded && step_max_rounds > 0 && levels - rounds_at_entry >= step_max_rounds && h_plan->open_total >= step_min_open)
-                return STCSP_OK;
+                return last_plan_fast ? read_plan(false) : STCSP_OK;  // (commit / donate / adopt work from the whole plan header)
         }
     }
 
