@@ -518,18 +518,18 @@ def main():
         avg_launch_s = k_time / max(k_launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # HBM traffic of the same kernel: FETCH_SIZE + WRITE_SIZE of every k_expand dispatch of one solve from this round's
-        # separate --pmc passes (tools/profile_r03.sh; a PMC run cannot be part of the timed bench), gfx950-corrected, per
+        # separate --pmc passes (tools/profile_r04.sh; a PMC run cannot be part of the timed bench), gfx950-corrected, per
         # launch like `achieved`; null when the committed profile was not taken on THIS engine source (hash mismatch)
         traffic = traffic_note = None
-        tf = REPO / "profiles" / "r03_p14_traffic.json"
+        tf = REPO / "profiles" / "r04_p14_traffic.json"
         if args.workload == WORKLOAD and not stepped and tf.exists() and k_launches:
             tj = json.loads(tf.read_text())
             if tj.get("engine_source_sha") == st.engine_source_sha():
                 traffic = tj["hbm_bytes_per_solve_corrected"] / (k_launches / args.steps)
-                traffic_note = ("profiles/r03_p14_traffic.json (engine source sha %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                traffic_note = ("profiles/r04_p14_traffic.json (engine source sha %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                 "command, gfx950-corrected, divided by this run's launches per solve" % tj["engine_source_sha"])
             else:
-                traffic_note = f"profiles/r03_p14_traffic.json was measured on another engine source ({tj.get('engine_source_sha')}): not quoted"
+                traffic_note = f"profiles/r04_p14_traffic.json was measured on another engine source ({tj.get('engine_source_sha')}): not quoted"
         p = model.problem.contents
         cfg = {"workload": f"{args.workload}.csp (token-identical to the reference's examples/{args.workload}.csp, regenerated by stcsp-solver_amd/instances.py; "
                            f"{p.n_vars} vars incl. aux, prefix K={p.prefix_k}, whole frontier resident in HBM)",

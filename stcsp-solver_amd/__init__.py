@@ -119,7 +119,7 @@ def engine_source_sha() -> str:
     """sha256 (first 16 hex digits) over the sources libstcsp_hip.so is built from: ties a committed PMC figure to the
     engine it was measured on (bench.py quotes profiles/*_traffic.json only when this matches)."""
     h = hashlib.sha256()
-    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("dev_*.hpp")) + [CSRC / "device_types.hpp", CSRC / "cset.cpp", CSRC / "cset.hpp"]):
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("dev_*.hpp")) + [CSRC / "device_types.hpp", CSRC / "cset.cpp", CSRC / "cset.hpp", CSRC / "sharded_native.hpp"]):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
