@@ -654,7 +654,7 @@ int stcsp_fmodel_program_sizes(stcsp_fmodel *h, long long *out, int n) {
     for (const stcsp::SetDesc &sd : g.sets) witems += sd.nitems - sd.nsmall;
     const long long v[11] = {(long long)(g.sets.size() * sizeof(stcsp::SetDesc)), (long long)(g.items.size() * 16), (long long)(g.itemrows.size() * 4),
                              witems * (long long)sizeof(stcsp::ItemDesc), (long long)(g.scope.size() * 4), (long long)(g.strides.size() * 4),
-                             (long long)(g.code.size() * 4), (long long)(g.cons.size() * sizeof(stcsp::ConDesc)), (long long)(g.tables.size() * 4),
+                             (long long)(g.code.size() * 4), (long long)(g.cons.size() * sizeof(stcsp::ConDesc)), (long long)((g.tables.size() + g.stables.size()) * 4),
                              (long long)(g.trans.size() * sizeof(stcsp::TransDesc) + g.transvals.size() * 4), (long long)(g.tdirect.size() * 4)};
     for (int i = 0; i < n && i < 11; i++) out[i] = v[i];
     return 11;

@@ -882,9 +882,10 @@ int SetManager::compile(FlatProgram &out) {
                 if (te.is_small || te.bitmap) {
                     auto pl = placed.find(key);
                     if (pl == placed.end()) {
-                        while (out.tables.size() & 3) out.tables.push_back(0u);
-                        Placed np{(int32_t)out.tables.size(), (int32_t)out.strides.size()};
-                        out.tables.insert(out.tables.end(), te.words.begin(), te.words.end());
+                        std::vector<uint32_t> &dst = te.is_small ? out.stables : out.tables;
+                        while (dst.size() & 3) dst.push_back(0u);
+                        Placed np{(int32_t)dst.size(), (int32_t)out.strides.size()};
+                        dst.insert(dst.end(), te.words.begin(), te.words.end());
                         out.strides.insert(out.strides.end(), te.strides.begin(), te.strides.end());
                         pl = placed.emplace(key, np).first;
                         if (te.pending) {

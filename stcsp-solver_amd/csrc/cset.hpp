@@ -72,6 +72,9 @@ struct FlatProgram {
     std::vector<TransDesc> trans;
     std::vector<ItemDesc> items;
     std::vector<uint32_t> itemrows, tables, nextpart;
+    std::vector<uint32_t> stables;  // row tables of the lane-revised items (ItemDesc::toff of IT_SMALL items points in here): a section of
+                                    // their own, so that a few hundred words every sweep reads are staged in LDS even when the tuple
+                                    // bitmaps in `tables` run to megabytes (digitinvader9: 268 words beside 4.9 MB)
     std::vector<int32_t> strides;
     int max_stack = 1;
     int max_cw = 1;

@@ -593,13 +593,27 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
     }
 }
 
-// the planner's verdict for the host (Progress::status / rounds / open_total): by the lane that wrote the plan words, after them
-__device__ __forceinline__ void mirror_plan(const Ctx &c, const Plan *p, int lane) {
-    if (c.progress && lane == 0) {
-        __hip_atomic_store(&c.progress->rounds, p->rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&c.progress->open_total, p->open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&c.progress->status, p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// the planner's verdict for the host (Progress::status / rounds / open_total [/ counters]): after the plan words have been written
+// (lane 0's plain stores are drained first, the words read back past the L1)
+__device__ __forceinline__ void mirror_plan(const Ctx &c, Plan *p, int lane) {
+    if (!c.progress) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int status = rfl(__hip_atomic_load(&p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (status == PS_DONE && lane < kMirrorCounters) {
+        // the search is over: lane k sums work counter k over its slots (every wavefront of the solve has flushed its counters
+        // and WAITED for those atomics before its workgroup's barrier: flush_env)
+        unsigned long long acc = 0;
+        for (int sl = 0; sl < kStatSlots; sl++) acc += __hip_atomic_load(&c.stats[sl * kStatWords + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c.progress->counters[lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    STCSP_REJOIN();
+    if (lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counters before the verdict that announces them)
+        __hip_atomic_store(&c.progress->rounds, __hip_atomic_load(&p->rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->open_total, __hip_atomic_load(&p->open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    STCSP_REJOIN();
 }
 __global__ void k_replan(Ctx c, unsigned next_launch) {
     if (blockIdx.x == 0 && threadIdx.x < 64) {

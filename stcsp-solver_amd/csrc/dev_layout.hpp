@@ -13,7 +13,7 @@ constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
 constexpr int kStatWords = 44;
-enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,
+enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,  // (the first kMirrorCounters: Progress::counters)
        ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
        ST_BATCHES, ST_BATCH_ITEMS, ST_CYC_BATCH, ST_BATCH_REFUSED, ST_CYC_BATCH_AB, ST_CYC_BATCH_DE, ST_BATCH_TUPLES,  // revise_batch (phases build)
        ST_CYC_STAGE, ST_BLOCKS, ST_CYC_FINAL, ST_ROUNDS_FINAL, ST_CYC_BLOCK,
@@ -105,11 +105,15 @@ struct Progress {
     long long rounds, open_total;
     int status;  // PlanStatus
     int pad;
+    // ... and, with the verdict PS_DONE, the work counters of the solve summed over their slots (ST_NODES .. ST_SKIPPED): the end of
+    // an unsharded search needs no copy either (the edge-log cursors and the state count are the words above)
+    unsigned long long counters[16];
 };
+constexpr int kMirrorCounters = 10;  // ST_NODES .. ST_SKIPPED
 
 struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
-        arr_off, code, divmagic, fstrides, words;
+        arr_off, code, stables, fstrides, words;  // stables: row tables of the lane-revised items (FlatProgram::stables)
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
 };
 

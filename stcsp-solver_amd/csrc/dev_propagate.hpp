@@ -662,6 +662,7 @@ __device__ __forceinline__ void flush_env(const Ctx &c, WaveEnv<DR> &E, int slot
         default: break;
     }
     if (v) atomicAdd(&c.stats[(slot % kStatSlots) * kStatWords + lane], v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed before the workgroup's barrier: the finalizing wavefront may sum them (mirror_plan)
     // RETURNING atomic whose result is consumed: the wavefront has then waited for it, so the error word is in place before
     // the workgroup's barrier and the end-of-round ticket behind it (k_expand) -- finalize_round must not plan another round
     // over an overflow. (A non-returning atomic is not waited for by the barrier's workgroup-scope release on gfx9.)
@@ -1250,7 +1251,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
                         if (it.arity < 3) D2 = 1u;
                         if (it.arity < 4) D3 = 1u;
                         uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                        const int tab = c.o.tables + it.toff;
+                        const int tab = c.o.stables + it.toff;  // (a section of its own: staged in LDS whenever it is small)
                         unsigned nev = 0;  // table rows this lane looks at
                         const int r1p = (it.r1 + 3) & ~3;  // small_row_stride: rows come four per 128-bit read
                         for (uint32_t m3 = D3; m3; m3 &= m3 - 1) {
@@ -1269,7 +1270,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
 #pragma unroll
                                     for (int g = 0; g < NQ; g++) {  // a non-empty group of D1 bits implies c4 + 4 g < r1p
                                         rr[g] = make_uint4(0u, 0u, 0u, 0u);
-                                        if (g == 0 || ((nib >> (4 * g)) & 15u)) rr[g] = P.v4c(base + c4 + 4 * g);
+                                        if (g == 0 || ((nib >> (4 * g)) & 15u)) rr[g] = P.v4(base + c4 + 4 * g);
                                     }
                                     uint32_t got = 0;
 #pragma unroll

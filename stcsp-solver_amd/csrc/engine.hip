@@ -290,16 +290,18 @@ struct stcsp_engine {
         o.transvals = put(prog.transvals.data(), prog.transvals.size() * 4);
         o.fstrides = put(prog.fstrides.data(), prog.fstrides.size() * 4);
         o.arr_off = put(mgr.array_off.data(), mgr.array_off.size() * 4);
-        {
-            // x / n == mulhi(x, ceil(2^32 / n)) for n <= 32, x < 2^27 (mixed-radix tuple decomposition of the general revision)
-            uint32_t magic[33] = {0};
-            for (uint32_t n = 1; n <= 32; n++) magic[n] = (uint32_t)((0x100000000ull + n - 1) / n);
-            magic[1] = 0xffffffffu;  // n = 1 never divides here (singletons are not enumerated)
-            o.divmagic = put(magic, sizeof magic);
-        }
         cut();
         o.itemrows = put(prog.itemrows.data(), prog.itemrows.size() * 4);
         cut();
+        // the row tables of the lane-revised items: next in line when they are small (every sweep reads them with per-lane
+        // addresses: out of LDS that is one ds_read_b128, out of global memory a 64-way divergent vector load per trip of the row
+        // loop -- digitinvader9's 268 words used to sit behind 4.9 MB of bitmaps in `tables`); big ones (the synthetic family:
+        // 122 KB) go behind the small sections that wavefront revisions need, so that they do not push those out of the prefix
+        const bool stables_early = prog.stables.size() <= 2048;
+        if (stables_early) {
+            o.stables = put(prog.stables.data(), prog.stables.size() * 4);
+            cut();
+        }
         o.hot_words = (int)img.size();
         {
             // ItemDesc records of the wavefront-revised items only (the lane-revised ones are read through their
@@ -315,6 +317,7 @@ struct stcsp_engine {
         if (lite) {
             // a LITE kernel never reads the bytecode: the tables come first, so that "everything the kernel reads" is a
             // prefix of the image (tables_end) -- what the big-workgroup variant stages
+            if (!stables_early) o.stables = put(prog.stables.data(), prog.stables.size() * 4);
             o.tables = put(prog.tables.data(), prog.tables.size() * 4);
             while (img.size() & 3) img.push_back(0u);
             tables_end = (int)img.size();
@@ -323,6 +326,10 @@ struct stcsp_engine {
         } else {
             o.code = put(prog.code.data(), prog.code.size() * 4);
             cut();
+            if (!stables_early) {
+                o.stables = put(prog.stables.data(), prog.stables.size() * 4);
+                cut();
+            }
             o.cons = put(prog.cons.data(), prog.cons.size() * sizeof(ConDesc));
             o.tables = put(prog.tables.data(), prog.tables.size() * 4);  // last: the part that may be big
             tables_end = 0;
@@ -789,6 +796,27 @@ struct stcsp_engine {
             std::this_thread::yield();
         }
         const volatile Progress *pr = h_progress;
+#ifndef STCSP_PHASES
+        if (pr->status == PS_DONE && !sharded && !dbg_rounds) {
+            // the end of an unsharded search: cursors, state count and the summed work counters are in the mirror too
+            if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
+            memset(h_stats, 0, kStatSlots * kStatWords * sizeof(unsigned long long));
+            for (int k = 0; k < kMirrorCounters; k++) h_stats[k] = pr->counters[k];
+            for (int i = 0; i < L.words; i++) h_ctl[i] = 0;
+            for (int r = 0; r < R; r++) h_ctl[L.edge0 + r * CST] = (uint32_t)pr->edge_seen[r];
+            h_ctl[L.misc0 + MISC_NSTATES * CST] = (uint32_t)pr->states_seen;
+            h_plan->status = PS_DONE;
+            h_plan->rounds = pr->rounds;
+            h_plan->open_total = pr->open_total;
+            for (int r = 0; r < R; r++) h_plan->edge_seen[r] = (unsigned)pr->edge_seen[r];
+            h_plan->states_seen = (unsigned)pr->states_seen;
+            levels = h_plan->rounds;
+            prog_have = false;
+            tail_fresh = true;
+            handled = true;
+            return STCSP_OK;
+        }
+#endif
         if (pr->status != PS_RUN) return STCSP_OK;  // (the caller reads everything)
         h_plan->status = PS_RUN;
         h_plan->rounds = pr->rounds;
@@ -804,14 +832,16 @@ struct stcsp_engine {
     bool last_plan_fast = false;  // h_plan holds only what read_plan_fast fills in (status, rounds, open nodes, export cursors)
     int read_plan(bool allow_fast = false) {
         last_plan_fast = false;
+        bool waited = false;  // the fast path has seen the burst's end already: what follows are the copies only
         if (allow_fast) {
             bool handled = false;
             int rc = read_plan_fast(handled);
             if (rc != STCSP_OK) return rc;
             if (handled) {
-                last_plan_fast = true;
+                last_plan_fast = h_plan->status == PS_RUN;
                 return STCSP_OK;
             }
+            waited = ctx.progress && mirror_ok;
         }
         HIPCHK(hipMemcpyAsync(h_plan, d_plan.p, kPlanHeader, hipMemcpyDeviceToHost, stream));
         // ... and, behind it, what finish() reads when this burst turns out to be the last one: the control block and the
@@ -819,7 +849,7 @@ struct stcsp_engine {
         if (!h_stats) HIPCHK(hipHostMalloc((void **)&h_stats, kStatSlots * kStatWords * sizeof(unsigned long long)));
         HIPCHK(hipMemcpyAsync(h_ctl, d_ctl.p, L.words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, kStatSlots * kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        if (streaming && ctx.progress) {
+        if (streaming && ctx.progress && !waited) {
             // instead of sleeping in the synchronisation: watch the progress mirror and ship what the launches
             // of the running burst have finished
             HIPCHK(hipEventRecord(ev_plan, stream));
