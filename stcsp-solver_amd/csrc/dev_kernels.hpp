@@ -33,7 +33,7 @@ __device__ __forceinline__ Ctx ctx_from(const uint32_t (&hot)[2]) {
 // accesses are LDS instructions whatever the compiler can or cannot infer about a pointer into it
 extern __shared__ __attribute__((aligned(16))) int stcsp_lds[];
 
-template <int DR, bool L, bool CS, bool LITE, int W = 1>
+template <int DR, int L, bool CS, bool LITE, int W = 1>
 __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk, int *ldom,
                             int sib_off, WaveEnv<DR> &env) {
     const Ctx c0 = ctx_from(hot);
@@ -664,7 +664,7 @@ __global__ void k_close_segment(Ctx c) {
 #ifndef STCSP_BIG_WAVES
 #define STCSP_BIG_WAVES 16  // wavefronts of a big workgroup
 #endif
-template <int DR, bool L, bool CS, bool LITE, bool BIG = false, int W = 1>
+template <int DR, int L, bool CS, bool LITE, bool BIG = false, int W = 1>
 __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_EXPAND_WAVES > 1 ? STCSP_EXPAND_WAVES : (LITE && DR == 1 ? STCSP_LITE_WAVES : (DR <= 2 ? STCSP_GEN_WAVES : STCSP_WIDE_WAVES)))) void k_expand(const Ctx *__restrict__ cp, const Plan *__restrict__ plan_arg, unsigned launch_id, uint32_t tab_gen) {
     const Ctx &c = *cp;
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
 // ------------------------------------------------------------------ k_probe (tests / diagnostics)
 // process_node on caller-provided blocks: the kernel-granularity check behind stcsp_engine_propagate.
 // One wavefront per block, every item dirty (seed 0); the propagated block and the outcome go back.
-template <int DR, bool L, bool CS, bool LITE>
+template <int DR, int L, bool CS, bool LITE>
 __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__restrict__ cp, uint32_t *blocks, int n, int set, uint32_t expire,
                                                                   int *outcome) {
     const Ctx &c = *cp;

@@ -6,9 +6,14 @@
 namespace stcsp {
 namespace dev {
 // ------------------------------------------------------------------ device helpers
-// View of the program image: L = true -> the workgroup's LDS copy, false -> global memory.
+// View of the program image. L = 1: the whole image is in the workgroup's LDS copy. L = 0: a prefix of `nlds` words is staged,
+// the rest is read from global memory -- every read decides at run time, which the compiler turns into FLAT loads through a
+// selected pointer (the general kernel had 185 of them; a flat load that lands in LDS goes through the vector-memory path first
+// and ties the LDS counter to the vector-memory one). L = 2 (round 4): the engine guarantees that EVERYTHING but the `tables`
+// section (tuple bitmaps: vc / uc / v4c) is staged -- v / u / v4 are plain LDS reads, the tables plain global loads; what
+// digitinvader's programs (12 KB of descriptors beside 4.9 MB of bitmaps) run under.
 // u(): wave-uniform read (scalar load / broadcast LDS read), v(): per-lane read.
-template <bool L>
+template <int L>
 struct Img {
     const uint32_t *p;    // the image in global memory
     const uint32_t *lds;  // its staged copy: the whole image when L, else the first `nlds` words
@@ -30,34 +35,47 @@ __device__ __forceinline__ int kload(const void *base, int idx) {
     return ((kptr)(const __attribute__((address_space(1))) int *)base)[idx];
 }
 template <>
-__device__ __forceinline__ int Img<true>::v(int off) const { return (int)lds[off]; }
+__device__ __forceinline__ int Img<1>::v(int off) const { return (int)lds[off]; }
 template <>
-__device__ __forceinline__ uint4 Img<true>::v4(int off) const { return *(const uint4 *)(lds + off); }
+__device__ __forceinline__ uint4 Img<1>::v4(int off) const { return *(const uint4 *)(lds + off); }
 template <>
-__device__ __forceinline__ int Img<true>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+__device__ __forceinline__ int Img<1>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
 template <>
-__device__ __forceinline__ int Img<true>::vc(int off) const { return (int)lds[off]; }
+__device__ __forceinline__ int Img<1>::vc(int off) const { return (int)lds[off]; }
 template <>
-__device__ __forceinline__ uint4 Img<true>::v4c(int off) const { return *(const uint4 *)(lds + off); }
+__device__ __forceinline__ uint4 Img<1>::v4c(int off) const { return *(const uint4 *)(lds + off); }
 template <>
-__device__ __forceinline__ int Img<true>::uc(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+__device__ __forceinline__ int Img<1>::uc(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+// everything but the tables staged
+template <>
+__device__ __forceinline__ int Img<2>::v(int off) const { return (int)lds[off]; }
+template <>
+__device__ __forceinline__ uint4 Img<2>::v4(int off) const { return *(const uint4 *)(lds + off); }
+template <>
+__device__ __forceinline__ int Img<2>::u(int off) const { return __builtin_amdgcn_readfirstlane((int)lds[off]); }
+template <>
+__device__ __forceinline__ int Img<2>::vc(int off) const { return (int)p[off]; }
+template <>
+__device__ __forceinline__ uint4 Img<2>::v4c(int off) const { return *(const uint4 *)(p + off); }
+template <>
+__device__ __forceinline__ int Img<2>::uc(int off) const { return kload(p, off); }
 // image larger than the LDS budget: a prefix of hot sections is staged, the rest is read from HBM/L2
 template <>
-__device__ __forceinline__ int Img<false>::v(int off) const { return off < nlds ? (int)lds[off] : (int)p[off]; }
+__device__ __forceinline__ int Img<0>::v(int off) const { return off < nlds ? (int)lds[off] : (int)p[off]; }
 template <>
-__device__ __forceinline__ uint4 Img<false>::v4(int off) const {
+__device__ __forceinline__ uint4 Img<0>::v4(int off) const {
     return off < nlds ? *(const uint4 *)(lds + off) : *(const uint4 *)(p + off);
 }
 template <>
-__device__ __forceinline__ int Img<false>::u(int off) const {
+__device__ __forceinline__ int Img<0>::u(int off) const {
     return off < nlds ? __builtin_amdgcn_readfirstlane((int)lds[off]) : kload(p, off);
 }
 template <>
-__device__ __forceinline__ int Img<false>::vc(int off) const { return (int)p[off]; }
+__device__ __forceinline__ int Img<0>::vc(int off) const { return (int)p[off]; }
 template <>
-__device__ __forceinline__ uint4 Img<false>::v4c(int off) const { return *(const uint4 *)(p + off); }
+__device__ __forceinline__ uint4 Img<0>::v4c(int off) const { return *(const uint4 *)(p + off); }
 template <>
-__device__ __forceinline__ int Img<false>::uc(int off) const { return kload(p, off); }
+__device__ __forceinline__ int Img<0>::uc(int off) const { return kload(p, off); }
 // After a lane-predicated statement (`if (lane < n) store`) that is followed by a return / break / continue the
 // compiler threads the two sides of the predicate straight into the join of the exits: to its uniformity
 // analysis the exit then hangs on a divergent branch, and one divergent loop exit turns every value carried
@@ -144,7 +162,7 @@ struct WaveEnv {
 // reference src/solveralgorithm.cpp:336-424). varinfo/curval are per-lane registers indexed by
 // scope position: varinfo = 1 + slot for lane-enumerated variables (value in lds_vals), 0 for
 // wave-uniform ones (value in curval).
-template <bool L>
+template <int L>
 __device__ int eval_program(const Ctx &c, const Img<L> &P, int pc0, int code_len, bool uses_valid, int lane, uint32_t varinfo, int curval,
                             const int *lds_vals, int *lds_stk) {
     // Operand stack: the top in `t`, the three entries below it in registers (s1 = most recent), anything deeper in
@@ -327,7 +345,7 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // scope variable has a supporting tuple (generalised arc consistency on this constraint; the
 // reference tightens bounds only, solveralgorithm.cpp:476-523 -- this prunes at least as much).
 // Returns false when a domain is wiped out. Rows of changed block words are OR-ed into `dirtyw`.
-template <int DR, bool L, bool LITE>
+template <int DR, int L, bool LITE>
 __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, const ConDesc &C, int item, int p, Dom<DR> &dom,
                              int lane, uint32_t &dirtyw, int *lds_vals, int *lds_stk, int *ldom, WaveStats &ws, bool &pruned) {
     const unsigned long long(&pm)[DR] = S.pm;
@@ -609,7 +627,7 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, cons
 
 // (Re)load the constraint-set part of the wavefront's environment: one per-lane read of the SetDesc words
 // (broadcast with readlane), then the per-lane pieces derived from it.
-template <int DR, bool L>
+template <int DR, int L>
 __device__ __forceinline__ void load_env(const Ctx &c, const Img<L> &P, int set, int lane, WaveEnv<DR> &E) {
     constexpr int W = (int)(sizeof(SetDesc) / 4);
     const uint32_t w = lane < W ? (uint32_t)P.v(c.o.sets + set * W + lane) : 0u;
@@ -725,7 +743,7 @@ __device__ unsigned emit_state_node(const Ctx &c, int lane, int ro, uint32_t *ou
 // round-based k_expand, the probe kernel) decide where children and leaves go.
 // OR the dirty rows of every block word in `cm` (bit l = word q*64 + l changed) into the lane-striped
 // dirty mask, four words per trip (independent reads).
-template <bool L>
+template <int L>
 __device__ __forceinline__ void mark_dirty_rows(const Img<L> &P, int rows_abs, int iw, int q, unsigned long long cm, int lane, uint32_t &dirtyw) {
     while (cm) {
         const int l0 = __ffsll((long long)cm) - 1;
@@ -749,7 +767,7 @@ __device__ __forceinline__ void mark_dirty_rows(const Img<L> &P, int rows_abs, i
 // every block word intersects itself with its partners' domains (SetDesc::next_off), repeated until
 // nothing changes (one pass for K = 2). Run after every change of the block, so that these arcs are
 // never work items and their prunings do not cost a sweep of their own. Returns false on a wipe-out.
-template <int DR, bool L>
+template <int DR, int L>
 __device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, Dom<DR> &dom, int lane, int *ldom, uint32_t &dirtyw) {
     const int base = S.next_abs;
     // what one entry allows: the partner's domain shifted into this word's value numbering
@@ -809,7 +827,7 @@ enum { BR_NOPEN = 0, BR_BASE = 1, BR_D0 = 2, BR_BITMAP = 3, BR_WPACK = 4 /* 2 wo
 static_assert(kMaxLowVars <= 6, "batch record layout");
 // per lane: the bits of dirty word `lane` that belong to wavefront-revised items WITH a tuple bitmap and a scope of
 // at most kBatchArity variables (the only ones revise_batch can take); worked out once per constraint set
-template <int DR, bool L>
+template <int DR, int L>
 __device__ __forceinline__ void load_bmmask(const Ctx &c, const Img<L> &P, int lane, WaveEnv<DR> &E) {
     uint32_t m = 0;
     if (lane < E.iw) {
@@ -860,7 +878,7 @@ __device__ __forceinline__ int row_prod_capped(int v) {  // factors <= 32; the p
     v = min(v * row_ror(v, 1), 1 << 15);
     return v;
 }
-template <int DR, bool L>
+template <int DR, int L>
 __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<DR> &dom, int lane, uint32_t &dirtyw, int *scr, int *clr,
                             int *ldom, WaveStats &ws, bool &pm_changed, int &first_item) {
     // The item records, scopes and strides sit in one run of image sections (engine.hip upload_program): staged in
@@ -1093,7 +1111,7 @@ __device__ int revise_batch(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, Dom<D
     return nb + __popcll(__ballot(noop));
 }
 
-template <int DR, bool L, bool CS, bool LITE>
+template <int DR, int L, bool CS, bool LITE>
 __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, int *ldom, Dom<DR> &dom,
                             const NodeHdr &hd, int gw, WaveEnv<DR> &S, BranchOut &bo, LeafOut<DR> &lo) {
     const int set = hd.set;

@@ -103,7 +103,7 @@ __device__ __forceinline__ WDom<W> wbroadcast(const WDom<W> &d, int srclane) {  
 // enumerated across lanes -- the product of their sizes in trips of 64, every lane decoding its own tuple -- the others by a
 // wave-uniform odometer. Evaluation = tuple bitmap look-up or the postfix program. A search longer than `budget` trips is
 // given up as "supported" (never prune without proof; leaves are exact: their product is 1).
-template <int W, bool L>
+template <int W, int L>
 __device__ bool exists_support_wide(const Ctx &c, const Img<L> &G, const ConDesc &C, int lane, const WDom<W> &D, int vlb, int mystride,
                                     int *lds_vals, int *lds_stk, unsigned long long &n_evals, bool &gave_up) {
     const int s = C.scope_len;
@@ -190,7 +190,7 @@ __device__ bool exists_support_wide(const Ctx &c, const Img<L> &G, const ConDesc
 
 // One point constraint at one time point, bounds consistency for every scope variable (enforcePointConsistencyAt,
 // src/solveralgorithm.cpp:476-523). Returns false on a wipe-out; `changedm`: scope positions whose domain shrank.
-template <int W, bool L>
+template <int W, int L>
 __device__ bool revise_bounds_wide(const Ctx &c, const Img<L> &G, const ConDesc &C, int p, int lane, int *ldom, int *lds_vals, int *lds_stk,
                                    unsigned long long &changedm, unsigned long long &n_evals, unsigned &n_skipped) {
     const int s = C.scope_len, NK1 = c.N * c.K;
@@ -305,7 +305,7 @@ struct BranchOutWide {
     int bvar, mid;  // children: values at bit positions <= mid / > mid of variable bvar at point 0
 };
 
-template <int DR, int W, bool L>
+template <int DR, int W, int L>
 __device__ int process_node_wide(const Ctx &c, const Img<L> &P, int lane, int *lds_vals, int *lds_stk, int *ldom, Dom<DR> &dom, const NodeHdr &hd,
                                  int gw, WaveEnv<DR> &S, BranchOutWide &bo, LeafOut<DR> &lo) {
     const int set = hd.set;

@@ -125,6 +125,8 @@ struct stcsp_engine {
     bool compact_sweeps = false;  // some set has more than kCompactSweepItems small items: k_expand<.., .., true, ..>
     bool lite = false;            // no constraint needs the general wavefront revision: k_expand<.., .., .., true>
     bool big = false;             // 1024-thread workgroups around one LDS copy of a LITE program: k_expand<.., true, .., true, true>
+    int prefix_need = 0;          // image words that must be staged for the L = 2 kernels (0: not applicable)
+    bool prefix_complete = false; // ... and they are: general program, everything but cons / tables in the staged prefix
     bool interpreted = false;     // some wavefront-revised constraint has no tuple bitmap (postfix interpreter: uniformly expensive nodes)
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
@@ -336,6 +338,9 @@ struct stcsp_engine {
         }
         while (img.size() & 3) img.push_back(0u);
         o.words = (int)img.size();
+        // everything the general kernels read through v() / u() ends where the ConDesc array (host bookkeeping) and the tables
+        // begin: a staged prefix that reaches this far lets them run the L = 2 kernels (plain LDS reads, dev_propagate.hpp Img)
+        prefix_need = lite ? 0 : o.cons;
         HIPCHK(d_img.upload(img));
         HIPCHK(d_code.upload(prog.code));
         // direct transition tables: one look-up per leaf, may be MBs (up to 256 MB): not part of the image, and not uploaded as
@@ -444,6 +449,7 @@ struct stcsp_engine {
             int per_cu = 0;
             hipError_t e;
             const void *fn;
+            prefix_complete = false;  // (decided below, from what gets staged)
             switch (DR) {
                 case 1: fn = expand_fn<1>(); break;
                 case 2: fn = expand_fn<2>(); break;
@@ -477,6 +483,19 @@ struct stcsp_engine {
                         ctx.stage_words = 0;
                 }
             }
+            prefix_complete = !lite && !img_in_lds && !big && !compact_sweeps && mgr.W == 1 && prefix_need > 0 && ctx.stage_words >= prefix_need &&
+                              !(getenv("STCSP_PREFIX_KERNEL") && atoi(getenv("STCSP_PREFIX_KERNEL")) == 0);
+            if (prefix_complete) {  // the kernel that will run: its own occupancy
+                const void *f2;
+                switch (DR) {
+                    case 1: f2 = expand_fn<1>(); break;
+                    case 2: f2 = expand_fn<2>(); break;
+                    default: f2 = expand_fn<4>(); break;
+                }
+                int pc2 = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, f2, 256, lds_bytes) == hipSuccess && pc2 > 0) per_cu = pc2;
+                else prefix_complete = false;
+            }
             hipDeviceProp_t prop;
             if (e == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess)
                 max_blocks = per_cu * prop.multiProcessorCount;
@@ -488,7 +507,7 @@ struct stcsp_engine {
             }
             if (getenv("STCSP_DEBUG"))
                 fprintf(stderr, "[engine] %s kernel, image %d words (%s: %d words staged), per-wavefront LDS scratch %zu B (stack slots %d), LDS/workgroup %zu B, %d workgroups/CU -> grid %d\n",
-                        big ? "LITE big-workgroup" : lite ? "LITE" : "general", o.words, img_in_lds || big ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
+                        big ? "LITE big-workgroup" : lite ? "LITE" : prefix_complete ? "general (descriptors in LDS, tables global)" : "general", o.words, img_in_lds || big ? "in LDS" : "global", ctx.stage_words, scratch / 4, ctx.stack_slots, lds_bytes, per_cu, max_blocks);
         }
         return STCSP_OK;
     }
@@ -1059,6 +1078,7 @@ struct stcsp_engine {
         const void *fn = nullptr;
         if (mgr.W == 2) return (const void *)k_expand<DRT, false, false, false, false, 2>;
         if (mgr.W > 2) return (const void *)k_expand<DRT, false, false, false, false, 4>;
+        if (prefix_complete) return (const void *)k_expand<DRT, 2, false, false>;
         with_variant<DRT>([&](auto v) {
             constexpr int V = decltype(v)::value;
             fn = (const void *)k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
@@ -1085,6 +1105,10 @@ struct stcsp_engine {
         }
         if (mgr.W > 2) {
             hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 4>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
+            return;
+        }
+        if (prefix_complete) {
+            hipLaunchKernelGGL((k_expand<DRT, 2, false, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
             return;
         }
         with_variant<DRT>([&](auto v) {
