@@ -430,9 +430,9 @@ struct Model {
             std::vector<uint32_t> rec(TS, 0u);
             rec[0] = node[0];
             rec[1] = node[1];
-            rec[2] = (uint32_t)mgr.sets[node[2] & 0xffffu]->tag;
+            rec[2] = (uint32_t)mgr.sets[node[2] & stcsp::kSetMask]->tag;
             rec[3] = node[3];
-            rec[4] = node[2] >> 16;
+            rec[4] = node[2] >> stcsp::kSetBits;
             memcpy(rec.data() + kXferHdr, node.data() + 4, (size_t)NK * 4);
             donated.insert(donated.end(), rec.begin(), rec.end());
             open.pop_front();

@@ -57,15 +57,15 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         dom.r[q] = idx < c.NK ? node[4 + idx] : 0u;
     }
     // header word 2: constraint set (low 16 bits) | dirty seed (high 16 bits): 0 = revise every
-    // item (fresh state / root), 0xffff = nothing to revise (re-queued fixpoint), else 1 + the
+    // item (fresh state / root), kSeedNone = nothing to revise (re-queued fixpoint), else 1 + the
     // variable whose time-0 domain the parent just bisected -- the parent block was at its
     // fixpoint, so only items reading that word can have lost supports
     NodeHdr hd;
     hd.h0 = rflu(node[0]);
     hd.h1 = rflu(node[1]);
     const uint32_t w2 = rflu(node[2]);
-    hd.set = (int)(w2 & 0xffffu);
-    hd.seed = w2 >> 16;
+    hd.set = (int)(w2 & kSetMask);
+    hd.seed = w2 >> kSetBits;
     hd.expire = rflu(node[3]);
     // A wavefront does not stop after one expansion: it keeps the lower child of a bisection (or the
     // first node of a state its leaf just opened) in registers and expands it too, up to `chain`
@@ -179,8 +179,8 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         hd.h0 = rflu((uint32_t)stcsp_lds[sib]);                                            \
         hd.h1 = rflu((uint32_t)stcsp_lds[sib + 1]);                                        \
         const uint32_t sw2 = rflu((uint32_t)stcsp_lds[sib + 2]);                           \
-        hd.set = (int)(sw2 & 0xffffu);                                                     \
-        hd.seed = sw2 >> 16;                                                               \
+        hd.set = (int)(sw2 & kSetMask);                                                    \
+        hd.seed = sw2 >> kSetBits;                                                         \
         hd.expire = rflu((uint32_t)stcsp_lds[sib + 3]);                                    \
         _Pragma("unroll") for (int q = 0; q < DR; q++) {                                   \
             const int idx = q * 64 + lane;                                                 \
@@ -191,7 +191,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         if (oc == OC_FAIL) STCSP_PATH_END();
         if (oc == OC_BRANCH) {
             const int bvar = W > 1 ? bow.bvar : bo.bvar;
-            const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bvar + 1) << 16);
+            const uint32_t cw2 = (uint32_t)hd.set | ((uint32_t)(bvar + 1) << kSetBits);
             Dom<DR> child = dom;
             if constexpr (W > 1) {
                 // the bisection point falls into one chunk of the variable: chunks below it go to the lower child whole, those above to the upper one
@@ -247,7 +247,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
                 env.err = max(env.err, (unsigned)ERR_OUT_OVERFLOW);
                 return;
             }
-            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | 0xffff0000u, hd.expire, dom, lane);
+            store_node<DR>(out_region + (size_t)pos * c.NS, c, hd.h0, hd.h1, (uint32_t)hd.set | (kSeedNone << kSetBits), hd.expire, dom, lane);
             STCSP_PATH_END();
         }
         // leaf
@@ -1061,8 +1061,8 @@ __global__ __launch_bounds__(256) void k_donate(Ctx c, DonateArgs a, uint32_t *o
     const int TS = xfer_stride(c.N, c.K * c.W);
     uint32_t *rec = out + (size_t)gw * TS;
     const uint32_t w2 = node[2];
-    const uint32_t tag = (uint32_t)kload(c.img, c.o.sets + (int)(w2 & 0xffffu) * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
-    if (lane < kXferHdr) rec[lane] = lane == 0 ? node[0] : (lane == 1 ? node[1] : (lane == 2 ? tag : (lane == 3 ? node[3] : (lane == 4 ? w2 >> 16 : 0u))));
+    const uint32_t tag = (uint32_t)kload(c.img, c.o.sets + (int)(w2 & kSetMask) * (int)(sizeof(SetDesc) / 4) + (int)(offsetof(SetDesc, tag) / 4));
+    if (lane < kXferHdr) rec[lane] = lane == 0 ? node[0] : (lane == 1 ? node[1] : (lane == 2 ? tag : (lane == 3 ? node[3] : (lane == 4 ? w2 >> kSetBits : 0u))));
     for (int k = lane; k < c.NK; k += 64) rec[kXferHdr + k] = node[4 + k];
 }
 // k_adopt: received transfer records become open nodes of the segment k_open_segment has just opened
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_adopt(Ctx c, const uint32_t *recs, long
         return;
     }
     uint32_t *dst = c.arena + p->out_base + ((size_t)ro * p->out_cap + np) * c.NS;
-    if (lane < 4) dst[lane] = lane == 0 ? rec[0] : (lane == 1 ? rec[1] : (lane == 2 ? ((uint32_t)set | rec[4] << 16) : rec[3]));
+    if (lane < 4) dst[lane] = lane == 0 ? rec[0] : (lane == 1 ? rec[1] : (lane == 2 ? ((uint32_t)set | rec[4] << kSetBits) : rec[3]));
     for (int k = lane; k < c.NK; k += 64) dst[4 + k] = rec[kXferHdr + k];
 }
 

@@ -1133,7 +1133,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         if (seed == 0) {
             int left = S.nitems - lane * 32;
             dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
-        } else if (seed != 0xffffu) {
+        } else if (seed != kSeedNone) {
             dirtyw = (uint32_t)P.v(S.rows_abs + (int)(seed - 1) * S.iw + lane);  // word (0, seed var)
         }
     }
@@ -1155,7 +1155,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
     bool need_close = false;
     if (seed == 0) {
         need_close = S.next_abs >= 0;  // fresh state: the time shift may have broken any arc
-    } else if (seed != 0xffffu) {
+    } else if (seed != kSeedNone) {
         const int w = (int)seed - 1;  // the parent bisected time-0 word w and was at its fixpoint otherwise
 #pragma unroll
         for (int q = 0; q < DR; q++)

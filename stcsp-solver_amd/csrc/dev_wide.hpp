@@ -317,7 +317,7 @@ __device__ int process_node_wide(const Ctx &c, const Img<L> &P, int lane, int *l
         if (seed == 0) {
             const int left = S.nitems - lane * 32;
             dirtyw = left >= 32 ? 0xffffffffu : (left > 0 ? ((1u << left) - 1u) : 0u);
-        } else if (seed != 0xffffu) {
+        } else if (seed != kSeedNone) {
             dirtyw = (uint32_t)P.v(S.rows_abs + (int)(seed - 1) * S.iw + lane);  // word (0, seed variable)
         }
     }

@@ -21,6 +21,12 @@ constexpr int kMaxLowVars = 6;      // lane-enumerated scope variables per revis
 constexpr int kMaxScope = 64;       // scope variables per constraint (one lane each)
 constexpr int kCursorStride = 16;   // words between cursors (64 B: one cursor per cache line)
 constexpr uint32_t kRootTag = 0x7fffffffu;
+// node header word 2 = constraint-set ordinal (low kSetBits bits) | dirty seed (the rest): seed 0 = revise every item (fresh state /
+// root), kSeedNone = nothing to revise (a re-queued fixpoint), else 1 + the variable whose time-0 domain the parent bisected
+// (N <= 256, so 12 bits hold it). 20 bits of ordinal: a million constraint sets (round 3: 16 / 16 bits, 65,535 sets).
+constexpr int kSetBits = 20;
+constexpr uint32_t kSetMask = (1u << kSetBits) - 1u;
+constexpr uint32_t kSeedNone = (1u << (32 - kSetBits)) - 1u;
 // odometer steps (blocks of <= 64 tuples, ~1.1 k cycles each when the bitmap is in HBM) one bitmap revision may take; longer
 // ones are skipped. 4096 made juggling_b4_f5_nosym 15.8 ms (1.5 with 64) and digitinvader9 23.4 (20.8): a revision that
 // long rarely prunes enough to pay for itself. 16 is faster still but propagates less than the reference does

@@ -234,8 +234,8 @@ struct stcsp_engine {
     int upload_program() {
         int rc = mgr.compile(prog);
         if (rc != STCSP_OK) return fail(rc, "%s", mgr.error.c_str());
-        // node header word 2 = set ordinal (16 bits) | dirty seed << 16
-        if (prog.sets.size() > 0xffffu) return fail(STCSP_E_UNSUPPORTED, "%zu constraint sets; node records address at most 65535", prog.sets.size());
+        // node header word 2 = set ordinal (kSetBits bits) | dirty seed
+        if (prog.sets.size() > (size_t)kSetMask) return fail(STCSP_E_UNSUPPORTED, "%zu constraint sets; node records address at most %u", prog.sets.size(), kSetMask);
         // LITE: every wavefront-revised constraint is a tuple bitmap with at most one violating tuple. Its
         // revision then either cannot prune (two or more open variables: the product of the others exceeds the
         // forbidden set) or is the one-open-variable look-up, so the general enumeration (tuple lanes, odometer,
