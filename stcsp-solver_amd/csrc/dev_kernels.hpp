@@ -95,7 +95,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
 #ifdef STCSP_PHASES
     // (hipcc 7.2 fails on this one instantiation of the instrumented build -- "Illegal instruction detected:
     // V_CMP_NE_U32_e32 0, $src_shared_base" -- with the stack in it; the product build is not affected)
-    const bool use_sib = chain > 2 && !(DR == 4 && L && !LITE);  // (round 3: <4,true,false,false> fails the same way)
+    const bool use_sib = chain > 2 && !(DR == 4 && L && !LITE);  // (round 3: <4,true,false,false> fails the same way; round 4: the wide kernels too)
 #else
     const bool use_sib = chain > 2;
 #endif
@@ -458,11 +458,15 @@ __device__ void push_output(const Ctx &c, Plan *p, bool consumed_input, int lane
 // every value the decision needs is requested up front -- cursors and pool fill levels by the lanes
 // that own them, the plan's scalars once -- so the common case costs two round trips. The segment
 // being consumed is known without re-reading it (plan.count holds its counts as planned).
-__device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_launch) {
+struct Verdict {  // what finalize_round decided (wave-uniform): mirrored to the host without reading the plan back
+    int status;
+    long long rounds, open_total;
+};
+__device__ Verdict finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_launch, int parity0) {
     const CtlLayout L(c.world);
     const bool rl = lane < R;
-    // ---- one batch of independent loads
-    const int parity0 = p->parity;
+    // ---- one batch of independent loads (the round's parity comes from the launch's prologue: the cursor addresses below
+    // depend on it, reading it here would put a round trip in front of the batch)
     int sp = p->sp;
     const int tcount = rl ? (int)ald(&c.ctl[L.out(parity0, lane)]) : 0;
     const int tk = rl ? p->take[lane] : 0;
@@ -483,9 +487,10 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
     const long long total = wave_sum64(tcount), taken0 = wave_sum64(tk);
     int cnt = cnt_planned - tk;  // what is left of the segment this round consumed from
     if (rl) p->stack[sp - 1].count[lane] = cnt;
+    Verdict vd{PS_RUN, rounds + 1, open_total + total - taken0};
     if (lane == 0) {
-        p->open_total = open_total + total - taken0;
-        p->rounds = rounds + 1;
+        p->open_total = vd.open_total;
+        p->rounds = vd.rounds;
     }
     if (rl) p->edge_seen[lane] = (unsigned)edges_r;
     if (lane == 0) p->states_seen = ns_l;
@@ -501,7 +506,8 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
                 p->status = PS_STACK_FULL;
                 close_gate(p, next_launch);
             }
-            return;
+            vd.status = PS_STACK_FULL;
+            return vd;
         }
         if (rl) p->stack[sp].count[lane] = tcount;
         if (lane == 0) {
@@ -523,7 +529,8 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
             p->status = PS_HOST;
             close_gate(p, next_launch);
         }
-        return;
+        vd.status = PS_HOST;
+        return vd;
     }
     while (sp > 0 && wave_sum64(cnt) == 0) {  // drop exhausted segments from the top (rare: extra round trips)
         arena_top = p->stack[sp - 1].base;
@@ -540,7 +547,8 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
             p->status = PS_DONE;
             close_gate(p, next_launch);
         }
-        return;
+        vd.status = PS_DONE;
+        return vd;
     }
     if (!in_known) {
         in_base = p->stack[sp - 1].base;
@@ -572,7 +580,8 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
             p->status = status;
             close_gate(p, next_launch);
         }
-        return;
+        vd.status = status;
+        return vd;
     }
     const int parity = parity0 ^ 1;
     if (rl) {
@@ -591,15 +600,14 @@ __device__ void finalize_round(const Ctx &c, Plan *p, int lane, unsigned next_la
         p->status = PS_RUN;
         set_gate(p, next_launch, R * maxtake);
     }
+    return vd;
 }
 
-// the planner's verdict for the host (Progress::status / rounds / open_total [/ counters]): after the plan words have been written
-// (lane 0's plain stores are drained first, the words read back past the L1)
-__device__ __forceinline__ void mirror_plan(const Ctx &c, Plan *p, int lane) {
+// the planner's verdict for the host (Progress::status / rounds / open_total [/ counters]); the values come in registers -- reading
+// the plan back would be three more dependent round trips at the end of every round
+__device__ __forceinline__ void mirror_plan(const Ctx &c, const Verdict &vd, int lane) {
     if (!c.progress) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int status = rfl(__hip_atomic_load(&p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (status == PS_DONE && lane < kMirrorCounters) {
+    if (vd.status == PS_DONE && lane < kMirrorCounters) {
         // the search is over: lane k sums work counter k over its slots (every wavefront of the solve has flushed its counters
         // and WAITED for those atomics before its workgroup's barrier: flush_env)
         unsigned long long acc = 0;
@@ -608,17 +616,23 @@ __device__ __forceinline__ void mirror_plan(const Ctx &c, Plan *p, int lane) {
     }
     STCSP_REJOIN();
     if (lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counters before the verdict that announces them)
-        __hip_atomic_store(&c.progress->rounds, __hip_atomic_load(&p->rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&c.progress->open_total, __hip_atomic_load(&p->open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&c.progress->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (vd.status == PS_DONE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counters before the verdict that announces them)
+        __hip_atomic_store(&c.progress->rounds, vd.rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->open_total, vd.open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&c.progress->status, vd.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     STCSP_REJOIN();
 }
 __global__ void k_replan(Ctx c, unsigned next_launch) {
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         plan_next(c, c.plan, threadIdx.x, next_launch);
-        mirror_plan(c, c.plan, threadIdx.x);
+        // (rare: once per burst at most -- the plan words are read back, lane 0's stores drained first)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Verdict vd;
+        vd.status = rfl(__hip_atomic_load(&c.plan->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        vd.rounds = __hip_atomic_load(&c.plan->rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vd.open_total = __hip_atomic_load(&c.plan->open_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mirror_plan(c, vd, threadIdx.x);
     }
 }
 // sharded commit: open an output segment of `cap` slots per region / close it again
@@ -673,54 +687,63 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     // work waits for. A planner that stops (done, pool full, host needed) leaves the gate on the launch that has just run: the
     // rest of the burst fails this test -- no separate look at the status word.
     static_assert(offsetof(Plan, gate) == 0, "the gate is the plan's first word");
+    // ---- ONE batch of independent loads before anything is waited for: the gate, the plan words of the round (through the plan
+    // ARGUMENT, not through the pointer inside *cp), the context words the prologue needs and the register copy of the context.
+    // (Round 3's prologue was a chain of a dozen dependent scalar loads -- gate, then *cp, then cp->progress, then cp->plan, then
+    // plan->rounds, then stage_words, then img, ... -- eight of them first touches of a cache line after the launch boundary, on
+    // the critical path of every round. The empty asm below pins the batch in front of the gate test.)
+    const kptr pk = (kptr)(const __attribute__((address_space(1))) int *)plan_arg;
     const unsigned long long gate = ((const __attribute__((address_space(4))) unsigned long long *)(const __attribute__((address_space(1))) unsigned long long *)plan_arg)[0];
-    if ((unsigned)(gate >> 32) != launch_id) return;  // another launch's round (this workgroup is late, or the burst ran past a stop)
+    auto pl = [&](size_t off) { return (uint32_t)pk[(int)(off / 4)]; };
+    const uint32_t p_in_lo = pl(offsetof(Plan, in_base)), p_in_hi = pl(offsetof(Plan, in_base) + 4);
+    const uint32_t p_out_lo = pl(offsetof(Plan, out_base)), p_out_hi = pl(offsetof(Plan, out_base) + 4);
+    const uint32_t p_in_cap = pl(offsetof(Plan, in_cap)), p_out_cap = pl(offsetof(Plan, out_cap)), p_cand_cap = pl(offsetof(Plan, cand_cap));
+    const uint32_t p_parity = pl(offsetof(Plan, parity)), p_rounds = pl(offsetof(Plan, rounds));
+    const int c_stage_words = c.stage_words, c_NK = c.NK, c_stack_slots = c.stack_slots, c_sib_depth = c.sib_depth, c_world = c.world;
+    const uint32_t *const c_img = c.img;
+    uint32_t *const c_arena = c.arena, *const c_cand = c.cand, *const c_ctl = c.ctl;
+    Progress *const c_progress = c.progress;
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t hot[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
+    asm volatile("" ::"s"(p_in_lo), "s"(p_in_hi), "s"(p_out_lo), "s"(p_out_hi), "s"(p_in_cap), "s"(p_out_cap), "s"(p_cand_cap), "s"(p_parity), "s"(p_rounds),
+                 "s"(c_stage_words), "s"(c_NK), "s"(c_stack_slots), "s"(c_sib_depth), "s"(c_world), "s"(c_img), "s"(c_arena), "s"(c_cand), "s"(c_ctl), "s"(c_progress));
+    if ((unsigned)(gate >> 32) != launch_id) return;  // another launch's round (this workgroup is late, or the burst ran past a stop)
     const int n_slots = (int)(unsigned)gate;
     const int wpb = BIG ? STCSP_BIG_WAVES : 4;  // wavefronts per workgroup
     // workgroups without a node slot leave at once; the ticket below counts the working ones only
     if ((int)blockIdx.x * wpb >= n_slots) return;
     const unsigned n_working = (unsigned)min((n_slots + wpb - 1) / wpb, (int)gridDim.x);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && c.progress)  // (the streaming export's "the round before this one has ended")
-        __hip_atomic_store(&c.progress->started, (unsigned long long)(kload(c.plan, (int)(offsetof(Plan, rounds) / 4)) + 1), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    const int img_words = (c.stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c_progress)  // (the streaming export's "the round before this one has ended")
+        __hip_atomic_store(&c_progress->started, (unsigned long long)(p_rounds + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int img_words = (c_stage_words + 3) & ~3;  // L: the whole image; else a prefix of hot sections (or 0)
     const unsigned long long t_k0 = PHASE_NOW();
     (void)t_k0;
     if (img_words) {
-        const uint4 *src = (const uint4 *)c.img;
+        const uint4 *src = (const uint4 *)c_img;
         uint4 *dst = (uint4 *)smem;
         for (int k = threadIdx.x; k < img_words / 4; k += (BIG ? STCSP_BIG_WAVES * 64 : 256)) dst[k] = src[k];
         __syncthreads();
     }
-    const int per_wave = wave_scratch_words(c.NK, c.stack_slots, LITE, c.sib_depth);
+    const int per_wave = wave_scratch_words(c_NK, c_stack_slots, LITE, c_sib_depth);
     int *lds_vals = smem + img_words + wib * per_wave;
     int *lds_stk = lds_vals + kMaxLowVars * 64;
-    int *ldom = LITE ? lds_vals : lds_stk + c.stack_slots * 64;  // NK-word AND-accumulator of this wavefront, then its counters
-    const int sib_off = img_words + wib * per_wave + wave_sib_offset(c.NK, c.stack_slots, LITE);  // word offset in the launch's LDS
-    Img<L> P{c.img, (const uint32_t *)smem, c.stage_words};
-    // the plan is read through the constant address space (scalar loads): a load through a generic pointer is a
-    // source of divergence to the compiler, and one divergent loop exit makes every value carried round the
-    // slot and chain loops a VGPR
+    int *ldom = LITE ? lds_vals : lds_stk + c_stack_slots * 64;  // NK-word AND-accumulator of this wavefront, then its counters
+    const int sib_off = img_words + wib * per_wave + wave_sib_offset(c_NK, c_stack_slots, LITE);  // word offset in the launch's LDS
+    Img<L> P{c_img, (const uint32_t *)smem, c_stage_words};
     ExpandArgs a;
-    {
-        auto pl = [&](size_t off) { return (uint32_t)kload(c.plan, (int)(off / 4)); };
-        auto pl64 = [&](size_t off) { return (unsigned long long)pl(off) | (unsigned long long)pl(off + 4) << 32; };
-        a.in_base = c.arena + pl64(offsetof(Plan, in_base));
-        a.in_cap = pl(offsetof(Plan, in_cap));
-        a.out_base = c.arena + pl64(offsetof(Plan, out_base));
-        a.out_cap = pl(offsetof(Plan, out_cap));
-        a.cand_base = c.cand;
-        a.cand_cap = pl(offsetof(Plan, cand_cap));
-        a.parity = (int)pl(offsetof(Plan, parity));
-    }
+    a.in_base = c_arena + ((unsigned long long)p_in_hi << 32 | p_in_lo);
+    a.in_cap = p_in_cap;
+    a.out_base = c_arena + ((unsigned long long)p_out_hi << 32 | p_out_lo);
+    a.out_cap = p_out_cap;
+    a.cand_base = c_cand;
+    a.cand_cap = p_cand_cap;
+    a.parity = (int)p_parity;
     const int total_waves = gridDim.x * wpb;
     const unsigned long long t_k1 = PHASE_NOW();
     (void)t_k1;
     WaveEnv<DR> env;
-    uint32_t hot[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) hot[q] = q * 64 + lane < kCtxWords ? ((const uint32_t *)cp)[q * 64 + lane] : 0u;
     {
         // the state table's generation changes with every solve; the device copy of the context does not have to: the launch
         // brings it along and it goes straight into the register copy the node loops read
@@ -736,10 +759,10 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
     // the wavefront whose share happened to be the dearest. The ticket for the NEXT slot is requested before the current one is
     // expanded (its latency disappears behind the node load); kSlotCursors counters deal interleaved tickets.
     {
-        const CtlLayout L_(c.world);
+        const CtlLayout L_(c_world);
         const int ncur = min(kSlotCursors, (int)gridDim.x);  // (a grid smaller than the counters: every residue needs a workgroup)
         const int cur = (int)blockIdx.x % ncur;
-        uint32_t *cursor = c.ctl + L_.slotcur0 + cur * CST;
+        uint32_t *cursor = c_ctl + L_.slotcur0 + cur * CST;
         for (int gw = blockIdx.x * wpb + wib; gw < n_slots;) {
             unsigned ticket = 0;
             if (lane == 0) ticket = atomicAdd(cursor, 1u);
@@ -772,8 +795,8 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
 #endif
             const unsigned long long t_k2 = PHASE_NOW();
             (void)t_k2;
-            finalize_round(c, c.plan, lane, launch_id + 1u);
-            mirror_plan(c, c.plan, lane);
+            const Verdict vd = finalize_round(c, c.plan, lane, launch_id + 1u, a.parity);
+            mirror_plan(c, vd, lane);
 #ifdef STCSP_PHASES
             if (lane == 0) {
                 add_stats(c, 0, ST_CYC_FINAL, PHASE_NOW() - t_k2);

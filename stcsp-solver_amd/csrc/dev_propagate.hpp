@@ -1288,7 +1288,14 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
 #pragma unroll
                                     for (int g = 0; g < NQ; g++) {  // a non-empty group of D1 bits implies c4 + 4 g < r1p
                                         rr[g] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef STCSP_PHASES
+                                        // (hipcc 7.2 fails on the instrumented build with a selected-pointer 128-bit read here --
+                                        // "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" -- the diagnostic build reads the
+                                        // global copy of the section under the partly-staged kernels)
+                                        if (g == 0 || ((nib >> (4 * g)) & 15u)) rr[g] = L == 0 ? P.v4c(base + c4 + 4 * g) : P.v4(base + c4 + 4 * g);
+#else
                                         if (g == 0 || ((nib >> (4 * g)) & 15u)) rr[g] = P.v4(base + c4 + 4 * g);
+#endif
                                     }
                                     uint32_t got = 0;
 #pragma unroll

@@ -485,6 +485,9 @@ struct stcsp_engine {
             }
             prefix_complete = !lite && !img_in_lds && !big && !compact_sweeps && mgr.W == 1 && prefix_need > 0 && ctx.stage_words >= prefix_need &&
                               !(getenv("STCSP_PREFIX_KERNEL") && atoi(getenv("STCSP_PREFIX_KERNEL")) == 0);
+#ifdef STCSP_PHASES
+            if (DR == 4) prefix_complete = false;
+#endif
             if (prefix_complete) {  // the kernel that will run: its own occupancy
                 const void *f2;
                 switch (DR) {
@@ -1059,6 +1062,14 @@ struct stcsp_engine {
 
     // kernel variant: whole image in LDS or not (L), compacted sweeps (sets with > kCompactSweepItems small
     // items: CS), no general wavefront revision (LITE)
+    // (the instrumented build, -DSTCSP_PHASES, cannot be compiled for <4, image in LDS, general>: hipcc 7.2 stops with "Illegal
+    // instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" in those instantiations; there the same programs run the
+    // partly-staged kernels instead. The product build has them all.)
+#ifdef STCSP_PHASES
+#define STCSP_VARIANT(DRT, V) (((DRT) == 4 && ((V) & 5) == 4) ? ((V) & ~4) : (V))
+#else
+#define STCSP_VARIANT(DRT, V) (V)
+#endif
     template <int DRT, typename F>
     void with_variant(F &&f) const {
         const int v = (img_in_lds || big ? 4 : 0) | (compact_sweeps ? 2 : 0) | (lite ? 1 : 0);
@@ -1078,9 +1089,12 @@ struct stcsp_engine {
         const void *fn = nullptr;
         if (mgr.W == 2) return (const void *)k_expand<DRT, false, false, false, false, 2>;
         if (mgr.W > 2) return (const void *)k_expand<DRT, false, false, false, false, 4>;
+#ifdef STCSP_PHASES
+        if constexpr (DRT != 4)  // (see STCSP_VARIANT)
+#endif
         if (prefix_complete) return (const void *)k_expand<DRT, 2, false, false>;
         with_variant<DRT>([&](auto v) {
-            constexpr int V = decltype(v)::value;
+            constexpr int V = STCSP_VARIANT(DRT, decltype(v)::value);
             fn = (const void *)k_expand<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
             if constexpr ((V & 5) == 5)
                 if (big) fn = (const void *)k_expand<DRT, true, (V & 2) != 0, true, true>;
@@ -1091,7 +1105,7 @@ struct stcsp_engine {
     const void *probe_fn() const {
         const void *fn = nullptr;
         with_variant<DRT>([&](auto v) {
-            constexpr int V = decltype(v)::value;
+            constexpr int V = STCSP_VARIANT(DRT, decltype(v)::value);
             fn = (const void *)k_probe<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>;
         });
         return fn;
@@ -1107,12 +1121,15 @@ struct stcsp_engine {
             hipLaunchKernelGGL((k_expand<DRT, false, false, false, false, 4>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
             return;
         }
+#ifdef STCSP_PHASES
+        if constexpr (DRT != 4)
+#endif
         if (prefix_complete) {
             hipLaunchKernelGGL((k_expand<DRT, 2, false, false>), dim3(max_blocks), dim3(256), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
             return;
         }
         with_variant<DRT>([&](auto v) {
-            constexpr int V = decltype(v)::value;
+            constexpr int V = STCSP_VARIANT(DRT, decltype(v)::value);
             if constexpr ((V & 5) == 5)
                 if (big) {
                     hipLaunchKernelGGL((k_expand<DRT, true, (V & 2) != 0, true, true>), dim3(max_blocks), dim3(STCSP_BIG_WAVES * 64), lds_bytes, stream, cp, (const Plan *)d_plan.p, launch_seq++, ctx.tab_gen);
@@ -1127,7 +1144,7 @@ struct stcsp_engine {
     void launch_probe(unsigned grid, uint32_t *blocks, int n, int set, uint32_t expire, int *outcome) {
         const Ctx *cp = (const Ctx *)d_ctx.p;
         with_variant<DRT>([&](auto v) {
-            constexpr int V = decltype(v)::value;
+            constexpr int V = STCSP_VARIANT(DRT, decltype(v)::value);
             hipLaunchKernelGGL((k_probe<DRT, (V & 4) != 0, (V & 2) != 0, (V & 1) != 0>), dim3(grid), dim3(256), lds_bytes, stream, cp, blocks, n, set,
                                expire, outcome);
         });
