@@ -1209,6 +1209,40 @@ __global__ __launch_bounds__(256) void k_tabulate(TabArgs a, uint32_t *bitmap) {
     if (lane == 32 && t - lane + 32 < a.product) bitmap[w0 + 1] = (uint32_t)(m >> 32);
 }
 
+// Start of a solve in ONE launch: zero the control block, the statistics and the out-degree mirror; the plan header (with the
+// pool capacities), the root's table entry, its key and its search node come out of a pinned host buffer the kernel reads
+// directly. (Round 3: three memsets and seven small host-to-device copies, each its own command in front of the first k_expand.)
+struct BeginArgs {
+    uint32_t *ctl;
+    int ctl_words, nstates_word;
+    unsigned long long *stats;
+    int stats_words;
+    uint32_t *sdeg;
+    unsigned long long sdeg_words;
+    uint32_t *plan_dst;
+    int plan_words;          // header + first segment, in 32-bit words
+    const uint32_t *stage;   // pinned host memory: [plan words | root entry (esz words) | root node (NS words)]
+    uint32_t *entry_dst;     // null: this rank does not hold the root
+    int esz;
+    uint32_t *keys_dst;
+    int KL;
+    uint32_t *node_dst;
+    int NS;
+};
+__global__ __launch_bounds__(256) void k_begin(BeginArgs a) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = tid; i < (unsigned long long)a.ctl_words; i += nth) a.ctl[i] = (a.entry_dst && (int)i == a.nstates_word) ? 1u : 0u;
+    for (unsigned long long i = tid; i < (unsigned long long)a.stats_words; i += nth) a.stats[i] = 0ull;
+    for (unsigned long long i = tid; i < a.sdeg_words; i += nth) a.sdeg[i] = 0u;
+    for (unsigned long long i = tid; i < (unsigned long long)a.plan_words; i += nth) a.plan_dst[i] = a.stage[i];
+    if (a.entry_dst) {
+        const uint32_t *ent = a.stage + a.plan_words, *node = ent + a.esz;
+        for (unsigned long long i = tid; i < (unsigned long long)a.esz; i += nth) a.entry_dst[i] = ent[i];
+        for (unsigned long long i = tid; i < (unsigned long long)a.KL; i += nth) a.keys_dst[i] = ent[i];
+        for (unsigned long long i = tid; i < (unsigned long long)a.NS; i += nth) a.node_dst[i] = node[i];
+    }
+}
+
 // re-insert every state into a larger table
 __global__ void k_rehash(Ctx c, uint32_t n_states) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -961,7 +961,6 @@ struct stcsp_engine {
                     !(getenv("STCSP_STREAM_EXPORT") && atoi(getenv("STCSP_STREAM_EXPORT")) == 0);
         if (const char *sc = getenv("STCSP_STREAM_CHUNK")) stream_chunk_min = (size_t)std::max(1, atoi(sc));
         if (const char *sc = getenv("STCSP_STREAM_CHUNK_IDLE")) stream_chunk_idle = (size_t)std::max(1, atoi(sc));
-        if (d_sdeg.p) HIPCHK(hipMemsetAsync(d_sdeg.p, 0, d_sdeg.n * sizeof(uint32_t), stream));
         ev_x_used[0] = ev_x_used[1] = false;
         ev_k_used = false;
         memset(h_progress, 0, sizeof(Progress));
@@ -976,9 +975,7 @@ struct stcsp_engine {
         ev_used = 0;
         seconds_expand_kernel = 0;
         expand_launches = 0;
-        HIPCHK(hipMemsetAsync(d_ctl.p, 0, L.words * sizeof(uint32_t), stream));
         for (int i = 0; i < L.words; i++) h_ctl[i] = 0;
-        HIPCHK(hipMemsetAsync(d_stats.p, 0, kStatSlots * kStatWords * sizeof(unsigned long long), stream));
         if (++ctx.tab_gen == 0u) {  // (2^32 solves on one engine: start over with a clean table)
             HIPCHK(hipMemsetAsync(d_slots.p, 0, d_slots.n * sizeof(unsigned long long), stream));
             ctx.tab_gen = 1u;
@@ -992,36 +989,35 @@ struct stcsp_engine {
         h_plan->chain_thresh = chain_thresh;
         h_plan->chain_heavy = chain_heavy;
         h_plan->world = opt.world;
+        // ONE launch (k_begin) zeroes the control block, the statistics and the out-degree mirror and brings the plan header, the
+        // root's table entry, key and search node over from the pinned staging buffer [plan words | entry | node]
+        const size_t esz = (size_t)1 << ctx.tab_shift;
+        const size_t plan_words = (kPlanHeader + sizeof(DevSegment)) / 4;
+        static_assert((kPlanHeader + sizeof(DevSegment)) % 4 == 0, "plan header in words");
+        const size_t stage_words = plan_words + esz + ctx.NS;
+        if (h_begin_words < stage_words) {
+            if (h_begin) (void)hipHostFree(h_begin);
+            HIPCHK(hipHostMalloc((void **)&h_begin, stage_words * sizeof(uint32_t)));
+            h_begin_words = stage_words;
+        }
+        uint32_t *key = h_begin + plan_words, *slotw = key + esz - 2, *node = key + esz;
+        unsigned long long h = 0;
         if (opt.rank == 0) {
             // root state: Signature({}, 0) (solveralgorithm.cpp:951-954) = local state 0 of shard 0.
             // With an empty signature a leaf of set 0 must find it again, so the key is the plain
             // (tag 0); otherwise a reserved tag keeps it apart from a state with an all-zero signature.
-            // (staged in pinned memory: small copies from pageable memory block the host for ~10 us each)
-            const size_t esz = (size_t)1 << ctx.tab_shift;
-            const size_t stage_words = esz + 4 + ctx.NS;
-            if (h_begin_words < stage_words) {
-                if (h_begin) (void)hipHostFree(h_begin);
-                HIPCHK(hipHostMalloc((void **)&h_begin, stage_words * sizeof(uint32_t)));
-                h_begin_words = stage_words;
-            }
             // the root's table entry: [key ... | slot word {generation, state 0}]
-            uint32_t *key = h_begin, *slotw = h_begin + esz - 2, *one = h_begin + esz, *node = one + 4;
             for (size_t i = 0; i < esz; i++) key[i] = 0u;
             key[0] = ctx.sig_len == 0 ? 0u : kRootTag;
-            const unsigned long long h = key_hash(key, ctx.KL);
+            h = key_hash(key, ctx.KL);
             unsigned long long slot = ((unsigned long long)ctx.tab_gen << 32) | 0u;
             memcpy(slotw, &slot, sizeof slot);
-            one[0] = 1u;
-            HIPCHK(hipMemcpyAsync(d_state_keys.p, key, ctx.KL * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync((uint32_t *)d_slots.p + ((size_t)((uint32_t)h & ctx.slot_mask) << ctx.tab_shift), key, esz * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NSTATES * CST, one, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             n_states = 1;
             // root search node: initial domains at every point (variable.cpp:24-29), set 0
             for (int i = 0; i < ctx.NS; i++) node[i] = 0u;
             for (int c = 0; c < ctx.W; c++)
                 for (int p = 0; p < ctx.K; p++)
                     for (int v = 0; v < ctx.N; v++) node[4 + c * ctx.N * ctx.K + p * ctx.N + v] = init_chunk(v, c);
-            HIPCHK(hipMemcpyAsync(d_arena.p, node, ctx.NS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             h_plan->sp = 1;
             h_plan->stack[0].base = 0;
             h_plan->stack[0].cap = 1;
@@ -1030,9 +1026,35 @@ struct stcsp_engine {
             h_plan->open_total = 1;
         }
         h_plan->status = PS_DONE;
-        HIPCHK(hipMemcpyAsync(d_plan.p, h_plan, kPlanHeader + sizeof(DevSegment), hipMemcpyHostToDevice, stream));
-        int rc = push_caps();
-        if (rc != STCSP_OK) return rc;
+        sync_ctx();
+        h_plan->arena_words = d_arena.n;  // (what push_caps() sends after a pool has grown)
+        h_plan->slot_cap = (unsigned long long)ctx.slot_mask + 1;
+        h_plan->edge_cap = ctx.edge_cap;
+        h_plan->state_cap = ctx.state_cap;
+        h_plan->cand_cap = cand_cap;
+        memcpy(h_begin, h_plan, plan_words * 4);
+        {
+            BeginArgs ba{};
+            ba.ctl = d_ctl.p;
+            ba.ctl_words = L.words;
+            ba.nstates_word = L.misc0 + MISC_NSTATES * CST;
+            ba.stats = d_stats.p;
+            ba.stats_words = kStatSlots * kStatWords;
+            ba.sdeg = d_sdeg.p;
+            ba.sdeg_words = d_sdeg.p ? (unsigned long long)d_sdeg.n : 0ull;
+            ba.plan_dst = (uint32_t *)d_plan.p;
+            ba.plan_words = (int)plan_words;
+            ba.stage = h_begin;
+            ba.entry_dst = opt.rank == 0 ? (uint32_t *)d_slots.p + ((size_t)((uint32_t)h & ctx.slot_mask) << ctx.tab_shift) : nullptr;
+            ba.esz = (int)esz;
+            ba.keys_dst = d_state_keys.p;
+            ba.KL = ctx.KL;
+            ba.node_dst = d_arena.p;
+            ba.NS = ctx.NS;
+            const unsigned long long work = std::max<unsigned long long>(ba.sdeg_words, (unsigned long long)ba.stats_words);
+            hipLaunchKernelGGL(k_begin, dim3((unsigned)std::min<unsigned long long>(512, (work + 255) / 256 + 1)), dim3(256), 0, stream, ba);
+            HIPCHK(hipGetLastError());
+        }
         // (no synchronisation: everything above is ordered before the first launch on the stream, and the staging buffers
         // are not touched again before a later call has synchronised)
         begun = true;
