@@ -58,6 +58,9 @@ typedef struct stcsp_sharded_stats {
     int64_t nodes_donated, nodes_adopted; /* open search nodes this rank gave away / took over                 */
     int64_t candidates_sent, candidates_received;
     double seconds_collectives;           /* wall time inside the transport's calls                            */
+    double seconds_expand;                /* ... inside expand_local (launch rounds + their synchronisations)   */
+    double seconds_pack;                  /* ... packing the outboxes / serialising the set registry            */
+    double seconds_commit;                /* ... enqueueing commit / adopt (the kernels themselves run behind)  */
 } stcsp_sharded_stats;
 
 /* The engine must have been created with options.rank / options.world equal to the transport's (world 1: with

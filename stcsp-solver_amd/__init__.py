@@ -549,7 +549,8 @@ class ShardedOptions(C.Structure):
 
 class ShardedStats(C.Structure):
     _fields_ = [("supersteps", C.c_int64), ("nodes_donated", C.c_int64), ("nodes_adopted", C.c_int64),
-                ("candidates_sent", C.c_int64), ("candidates_received", C.c_int64), ("seconds_collectives", C.c_double)]
+                ("candidates_sent", C.c_int64), ("candidates_received", C.c_int64), ("seconds_collectives", C.c_double),
+                ("seconds_expand", C.c_double), ("seconds_pack", C.c_double), ("seconds_commit", C.c_double)]
 
 
 def _bind_sharded(lib):

@@ -796,6 +796,8 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     bool tail_fresh = false;  // h_ctl / h_stats hold the state after the last device work of the search (read_plan copied them)
+    bool ctl_fresh = false;   // h_ctl is what the copying read_plan brought and nothing has been enqueued since (sharded stepping: expand_local
+                              // needs the outbox cursors; a second copy + synchronisation of the control block costs ~25 us per superstep)
     // End of a burst. Fast path (the common case: the planner says "go on"): wait for the burst's end -- shipping finished parts
     // of the edge log meanwhile -- and take the planner's verdict from the pinned mirror the device wrote it to; no copies.
     // Anything else (done, a pool to grow, a translation, an error, a budget) takes the full read below.
@@ -890,6 +892,7 @@ struct stcsp_engine {
         }
         HIPCHK(hipStreamSynchronize(stream));
         levels = h_plan->rounds;
+        ctl_fresh = true;
         tail_fresh = !sharded;  // (the stepping interface enqueues commit / adopt / donate work between its reads)
         return STCSP_OK;
     }
@@ -941,6 +944,7 @@ struct stcsp_engine {
     unsigned launch_seq = 0;  // id of the next k_expand launch (Plan::gate)
     int replan() {
         tail_fresh = false;
+        ctl_fresh = false;
         hipLaunchKernelGGL(k_replan, dim3(1), dim3(64), 0, stream, ctx, launch_seq);
         HIPCHK(hipGetLastError());
         return STCSP_OK;
@@ -949,6 +953,7 @@ struct stcsp_engine {
     int begin() {
         HIPCHK(hipSetDevice(device));
         tail_fresh = false;
+        ctl_fresh = false;
         std::fill(edge_count.begin(), edge_count.end(), 0u);
         n_states = 0;
         truncated = false;
@@ -1406,6 +1411,7 @@ struct stcsp_engine {
                 HIPCHK(hipEventRecord(ev_pool[ev_used].first, stream));
             }
             tail_fresh = false;
+            ctl_fresh = false;
             for (int k = 0; k < burst; k++) {
                 switch (DR) {
                     case 1: launch_expand<1>(); break;
@@ -1631,7 +1637,7 @@ struct stcsp_engine {
         if (rc != STCSP_OK) return rc;
         if (getenv("STCSP_DEBUG"))
             fprintf(stderr, "[expand_local] %.3f ms, %lld rounds so far, streamed %zu\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, levels, streamed);
-        rc = read_ctl();  // outbox cursors for outbox()
+        rc = ctl_fresh ? parse_ctl() : read_ctl();  // outbox cursors for outbox() (the last burst's copying read_plan has them already)
         if (rc != STCSP_OK) return rc;
         host_view_fresh = true;
         if (left) *left = truncated ? 0 : (int64_t)h_plan->open_total;
@@ -1640,7 +1646,7 @@ struct stcsp_engine {
     // The first outbox() call after an expand_local packs the regions of EVERY peer (one kernel per
     // non-empty peer, one synchronisation), back to back in the pack buffer, so that the driver can hand
     // the whole buffer to one all-to-all-v; the other calls only read the cached slices.
-    int pack_outboxes() {
+    int pack_outboxes(bool sync = true) {
         if (d_pack.n < (size_t)opt.world * R * cand_cap * ctx.CS) HIPCHK(d_pack.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         pack_ptr.assign(opt.world, nullptr);
         pack_count.assign(opt.world, 0);
@@ -1657,14 +1663,14 @@ struct stcsp_engine {
             before += total;
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
+        if (sync) HIPCHK(hipStreamSynchronize(stream));  // (a driver that moves the records on another stream; the native loop's transports are ordered on this one)
         packed = true;
         return STCSP_OK;
     }
-    int outbox(int peer, void **ptr, int64_t *count) {
+    int outbox(int peer, void **ptr, int64_t *count, bool sync = true) {
         if (peer < 0 || peer >= opt.world) return fail(STCSP_E_INVALID, "peer out of range");
         if (!packed) {
-            int rc = pack_outboxes();
+            int rc = pack_outboxes(sync);
             if (rc != STCSP_OK) return rc;
         }
         *ptr = pack_ptr[peer];
@@ -1672,6 +1678,7 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     int commit(const void *records, int64_t count) {
+        ctl_fresh = false;
         if (!begun) return fail(STCSP_E_STATE, "commit before begin");
         if (fault_hit("commit")) return fail(STCSP_E_INTERNAL, "injected fault in commit");
         tail_fresh = false;
@@ -1726,6 +1733,7 @@ struct stcsp_engine {
 
     // ---- frontier redistribution (stcsp_engine.h): the oldest open nodes leave / received ones join
     int donate(int64_t want, void **ptr, int64_t *count) {
+        ctl_fresh = false;
         if (!begun || !sharded) return fail(STCSP_E_STATE, "donate is part of the sharded stepping interface (after begin)");
         if (fault_hit("donate")) return fail(STCSP_E_INTERNAL, "injected fault in donate");
         tail_fresh = false;
@@ -1775,6 +1783,7 @@ struct stcsp_engine {
         return STCSP_OK;
     }
     int adopt(const void *records, int64_t count) {
+        ctl_fresh = false;
         if (!begun || !sharded) return fail(STCSP_E_STATE, "adopt is part of the sharded stepping interface (after begin)");
         if (fault_hit("adopt")) return fail(STCSP_E_INTERNAL, "injected fault in adopt");
         tail_fresh = false;

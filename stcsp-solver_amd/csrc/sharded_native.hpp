@@ -108,11 +108,15 @@ inline int stcsp_solve_sharded_impl(stcsp_engine *e, const stcsp_transport *t, c
         int64_t left = 0;
         void *out_ptr0 = nullptr;
         std::fill(row.begin(), row.end(), 0);
-        if (pending == STCSP_OK && guard(e->expand_local(&left)) == STCSP_OK) {
+        auto t_ph = clock::now();
+        const bool expanded = pending == STCSP_OK && guard(e->expand_local(&left)) == STCSP_OK;
+        s.seconds_expand += std::chrono::duration<double>(clock::now() - t_ph).count();
+        t_ph = clock::now();
+        if (expanded) {
             for (int p = 0; p < world && pending == STCSP_OK; p++) {
                 void *ptr = nullptr;
                 int64_t cnt = 0;
-                if (guard(e->outbox(p, &ptr, &cnt)) == STCSP_OK) {
+                if (guard(e->outbox(p, &ptr, &cnt, /*sync=*/false)) == STCSP_OK) {  // (all_to_all_v is ordered on the engine's stream)
                     row[p] = cnt;
                     if (p == 0) out_ptr0 = ptr;  // (the engine packs the peers back to back: pack_outboxes)
                 }
@@ -121,6 +125,7 @@ inline int stcsp_solve_sharded_impl(stcsp_engine *e, const stcsp_transport *t, c
         const int32_t *blob = nullptr;
         int64_t blob_words = 0;
         if (pending == STCSP_OK) guard(stcsp_engine_sets_blob(e, &blob, &blob_words));
+        s.seconds_pack += std::chrono::duration<double>(clock::now() - t_ph).count();
         if (pending != STCSP_OK) {
             std::fill(row.begin(), row.end(), 0);
             row[world + 3] = 1;
@@ -205,8 +210,10 @@ inline int stcsp_solve_sharded_impl(stcsp_engine *e, const stcsp_transport *t, c
         s.candidates_sent += n_send;
         s.candidates_received += n_recv;
         // (an error from here on travels with the next superstep's count table, or with the final agreement)
+        t_ph = clock::now();
         guard(e->commit(e->d_recv_cand.p, n_recv));
         if (n_adopt && pending == STCSP_OK) guard(e->adopt(e->d_recv_nodes.p, n_adopt));
+        s.seconds_commit += std::chrono::duration<double>(clock::now() - t_ph).count();
         if (total_open == 0 && total_cands == 0) break;
     }
     if (pending == STCSP_OK) guard(e->finish());

@@ -21,5 +21,6 @@ for forced in ("0", "1"):
     c = e.counters()
     dt, s = best
     print(f"{name} forced={forced}: {dt*1e3:8.3f} ms  {c.search_nodes/dt/1e6:7.1f} M nodes/s  supersteps {s['supersteps']}  rounds {c.levels}  "
-          f"candidates {s['candidates_sent']}  collectives {s['seconds_collectives']*1e3:.3f} ms  per superstep {dt*1e3/s['supersteps']:.3f} ms", flush=True)
+          f"candidates {s['candidates_sent']}  per superstep {dt*1e3/s['supersteps']:.3f} ms = expand {s['seconds_expand']*1e3/s['supersteps']:.3f} + pack {s['seconds_pack']*1e3/s['supersteps']:.3f} "
+          f"+ collectives {s['seconds_collectives']*1e3/s['supersteps']:.3f} + commit {s['seconds_commit']*1e3/s['supersteps']:.3f}", flush=True)
     e.close()
