@@ -101,7 +101,7 @@ struct stcsp_engine {
     size_t arena_soft_words = 0;
     // expansions per slot and launch (expand_node): chain_small while a round has <= chain_thresh
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
-    // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 8 under the general kernels
+    // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 16 (round 3: 8) under the general kernels
     // (expensive nodes: fewer, longer rounds -- digitinvader9 27.2 -> 23.4 ms), 4 under the LITE ones
     // (partialorder_12/14/16 lose 3-10 % with 8), 2 when a constraint is interpreted (the juggling _nosym instances: a few thousand
     // uniformly expensive nodes, longer chains only serialise them: juggling_b6_f6_nosym 2.5 -> 1.8 ms); chain_big 4 since the sibling stack (2 before: partialorder_18 81 -> 74.5 ms,
@@ -675,6 +675,7 @@ struct stcsp_engine {
         // chain, so a region of an owner's outbox receives up to chain x max-take candidates per launch; the planner takes no
         // more nodes per region than the outboxes have room for (plan_next), so their size is independent of the batch: room
         // for 4,096 nodes per region and launch (world 8: 3.4 GB at 100-word records).
+        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 16);  // (what begin() will plan with: the outboxes are sized for it)
         cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * std::min(chunk_r, 4096), 4096) : 64);
         if (const char *ev = getenv("STCSP_CAND_CAP")) if (sharded && atoi(ev) > 0) cand_cap = (uint32_t)std::max(atoi(ev), 2 * std::max(chain_small, chain_big));  // tests: outboxes that fill up
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
@@ -988,7 +989,9 @@ struct stcsp_engine {
         memset(h_plan, 0, sizeof(Plan));
         chunk_r = chunk_r0;
         h_plan->chunk_r = chunk_r;
-        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 8);
+        // (general kernels: 16 since round 4 -- the time cap chain_heavy is what ends a slot there, the count only has to stay out of
+        // its way: digitinvader9 18.8 -> 17.9 ms, digitinvader7 10.1 -> 9.6 with 16 instead of 8; 24 the same; tools/env_sweep.py)
+        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 16);
         h_plan->chain_small = chain_small;
         h_plan->chain_big = chain_big;
         h_plan->chain_thresh = chain_thresh;
