@@ -241,16 +241,23 @@ struct stcsp_local_group {
         int rank;
     };
     std::vector<Member> members;
+    bool broken = false;  // a rank's copy failed: every later collective of the group fails at once instead of waiting for that rank
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);
         const unsigned long long gen = generation;
+        if (broken) return;
         if (++arrived == world) {
             arrived = 0;
             generation++;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            cv.wait(lk, [&] { return generation != gen || broken; });
         }
+    }
+    void give_up() {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
     }
 };
 
@@ -260,9 +267,13 @@ int local_all_gather_bytes(void *self, const void *mine, int64_t n, void *all) {
     stcsp_local_group *g = m->g;
     g->ptr[m->rank] = mine;
     g->barrier();
+    if (g->broken) {
+        g->errors[m->rank] = "a peer's transport call failed";
+        return -1;
+    }
     for (int r = 0; r < g->world; r++) memcpy((char *)all + (size_t)r * n, g->ptr[r], (size_t)n);
     g->barrier();  // (nobody's buffer is reused before everyone has copied)
-    return 0;
+    return g->broken ? -1 : 0;
 }
 int local_all_gather_i64(void *self, const int64_t *mine, int32_t n, int64_t *all) { return local_all_gather_bytes(self, mine, (int64_t)n * 8, all); }
 int local_all_to_all_v(void *self, const void *send, const int64_t *send_words, void *recv, const int64_t *recv_words, void *stream) {
@@ -276,6 +287,10 @@ int local_all_to_all_v(void *self, const void *send, const int64_t *send_words, 
     g->counts[m->rank] = send_words;
     g->device[m->rank] = dev;
     g->barrier();
+    if (g->broken) {
+        g->errors[m->rank] = "a peer's transport call failed";
+        return -1;
+    }
     size_t roff = 0;
     for (int p = 0; p < g->world && ok; p++) {
         size_t soff = 0;  // where this rank's part starts in peer p's send buffer
@@ -299,8 +314,9 @@ int local_all_to_all_v(void *self, const void *send, const int64_t *send_words, 
         roff += words;
     }
     ok = ok && hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
+    if (!ok) g->give_up();  // (the peers must not wait for this rank in the collectives to come)
     g->barrier();  // (send buffers may be reused from here on)
-    return ok ? 0 : -1;
+    return ok && !g->broken ? 0 : -1;
 }
 const char *local_last_error(void *self) {
     auto *m = (stcsp_local_group::Member *)self;
