@@ -97,6 +97,9 @@ ENGINE_SYMBOLS = [
     "stcsp_engine_propagate", "stcsp_engine_set_expand_budget", "stcsp_engine_node_bytes", "stcsp_engine_donate",
     "stcsp_engine_adopt",
 ]
+# include/stcsp_sharded.h: the superstep loop + in-process transport (libstcsp_hip.so), the RCCL transport (libstcsp_rccl.so)
+SHARDED_SYMBOLS_HIP = ["stcsp_engine_solve_sharded", "stcsp_local_group_create", "stcsp_local_group_transport", "stcsp_local_group_destroy"]
+SHARDED_SYMBOLS_RCCL = ["stcsp_rccl_unique_id", "stcsp_transport_rccl_create", "stcsp_transport_rccl_destroy"]
 HOST_SYMBOLS = [
     "stcsp_model_load_file", "stcsp_model_load_text", "stcsp_model_problem", "stcsp_model_free",
     "stcsp_host_last_error", "stcsp_model_constraint_string",

@@ -22,6 +22,21 @@ def test_engine_library_exports_every_declared_symbol(stcsp):
         assert hasattr(lib, n), n
 
 
+def test_sharded_header_symbols_are_exported(stcsp):
+    """include/stcsp_sharded.h: the superstep loop and the in-process transport live in libstcsp_hip.so, the RCCL transport in
+    libstcsp_rccl.so (which loads without a GPU too: it links librccl and libamdhip64)."""
+    subprocess.run(["make", "-C", str(stcsp.CSRC), "libstcsp_hip.so", "libstcsp_rccl.so"], check=True, capture_output=True)
+    names = declared("stcsp_sharded.h")
+    assert set(names) == set(stcsp.SHARDED_SYMBOLS_HIP) | set(stcsp.SHARDED_SYMBOLS_RCCL)
+    hip = C.CDLL(str(stcsp.CSRC / "libstcsp_hip.so"))
+    for n in stcsp.SHARDED_SYMBOLS_HIP:
+        assert hasattr(hip, n), n
+    rccl = C.CDLL(str(stcsp.CSRC / "libstcsp_rccl.so"))
+    for n in stcsp.SHARDED_SYMBOLS_RCCL:
+        assert hasattr(rccl, n), n
+    assert C.sizeof(stcsp.ShardedOptions) == 24 and C.sizeof(stcsp.ShardedStats) == 5 * 8 + 4 * 8
+
+
 def test_host_library_exports_every_declared_symbol(stcsp):
     lib = stcsp.host_lib()
     names = declared("stcsp_host.h")
