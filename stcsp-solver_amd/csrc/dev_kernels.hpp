@@ -1288,6 +1288,16 @@ __global__ void k_post_outdeg(EdgeView v, uint32_t *outdeg, uint8_t *alive) {
     alive[e] = 1;
     atomicAdd(&outdeg[er[0]], 1u);  // unsharded: the global id is the local index
 }
+// First round of the ok-fixpoint when the whole log was streamed: every state's flag (0 / 1) goes to the device array AND straight to
+// the pinned host array, the "somebody failed" word to pinned memory too -- no memsets in front, no copies behind.
+__global__ void k_post_mark_host(uint32_t n_states, const uint32_t *outdeg, uint8_t *fail, uint8_t *hfail, uint32_t *hchanged) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_states) return;
+    const uint8_t f = (s != 0 && outdeg[s] == 0) ? 1 : 0;  // the root is never marked (solveralgorithm.cpp:967-971)
+    fail[s] = f;
+    hfail[s] = f;
+    if (f) *hchanged = 1u;
+}
 __global__ void k_post_mark(uint32_t n_states, const uint32_t *outdeg, uint8_t *fail, uint32_t *changed) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 || s >= n_states) return;  // the root is never marked (solveralgorithm.cpp:967-971)
@@ -1371,8 +1381,11 @@ __global__ __launch_bounds__(256) void k_stream_keys(const uint32_t *keys, int K
     else if (j - 1 < sl)
         sig[(size_t)i * sl + (j - 1)] = (int32_t)v;
 }
+// (hsrc / hdst / hval: the pinned host arrays, or null. The LAST chunk of an export, when it is small, is written to the host by the
+// kernel itself beside the device copy -- one command instead of a kernel and three copies behind it; big chunks go by the copy
+// engine: a kernel that writes megabytes over the link holds its wave slots at the link's speed.)
 __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned long long base, unsigned long long dst_or, long long *osrc, long long *odst,
-                                                      int32_t *oval, uint32_t *sdeg) {
+                                                      int32_t *oval, uint32_t *sdeg, long long *hsrc, long long *hdst, int32_t *hval) {
     __shared__ unsigned long long tab[4][64];
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
@@ -1386,8 +1399,14 @@ __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned lon
             if (e >= v.pref[r + step]) r += step;
         const uint32_t *er = v.edges + ((size_t)r * v.edge_cap + v.from[r] + (e - v.pref[r])) * v.ES;
         tab[wib][lane] = (unsigned long long)(er - v.edges);
-        osrc[base + e] = (long long)(((unsigned long long)er[1] << 32) | er[0]);
-        odst[base + e] = (long long)(dst_or | er[2]);  // sharded runs: the local index becomes a global id (rank bits)
+        const long long es = (long long)(((unsigned long long)er[1] << 32) | er[0]);
+        const long long ed = (long long)(dst_or | er[2]);  // sharded runs: the local index becomes a global id (rank bits)
+        osrc[base + e] = es;
+        odst[base + e] = ed;
+        if (hsrc) {
+            hsrc[base + e] = es;
+            hdst[base + e] = ed;
+        }
         if (sdeg) atomicAdd(&sdeg[er[0]], 1u);         // unsharded: out-degrees for the ok-fixpoint's first round (the global id is the local index)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1397,8 +1416,11 @@ __global__ __launch_bounds__(256) void k_stream_edges(StreamView v, unsigned lon
     const int q64 = 64 / N, r64 = 64 % N;
     int r = lane / N, k = lane - r * N;
     int32_t *out = oval + (size_t)(base + e0) * N;
+    int32_t *hout = hval ? hval + (size_t)(base + e0) * N : nullptr;
     for (int w = lane; w < total; w += 64) {
-        out[w] = (int32_t)v.edges[tab[wib][r] + 4 + k];
+        const int32_t val = (int32_t)v.edges[tab[wib][r] + 4 + k];
+        out[w] = val;
+        if (hout) hout[w] = val;
         r += q64;
         k += r64;
         if (k >= N) {

@@ -1323,11 +1323,20 @@ struct stcsp_engine {
         const int N = ctx.N;
         const int xi = (int)(chunk_no++ & 1u);
         hipStream_t xs = xi ? xstream2 : xstream;  // (chunks touch disjoint ranges of the arrays)
+        // the last chunk of an export, when small: the kernel writes the host arrays itself (see k_stream_edges)
+        const bool zero_copy = final && M <= 8192 && !(getenv("STCSP_STREAM_ZC") && atoi(getenv("STCSP_STREAM_ZC")) == 0);
         hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, xs, v, (unsigned long long)streamed,
-                           sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p, sharded ? nullptr : d_sdeg.p);
+                           sharded ? (unsigned long long)opt.rank << STCSP_GID_SHIFT : 0ull, d_osrc.p, d_odst.p, d_oval.p, sharded ? nullptr : d_sdeg.p,
+                           zero_copy ? h_osrc : nullptr, zero_copy ? h_odst : nullptr, zero_copy ? h_oval : nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ev_x[xi], xs));
         ev_x_used[xi] = true;
+        if (zero_copy) {
+            HIPCHK(hipEventRecord(ev_c[xi], xs));
+            for (int r = 0; r < R; r++) streamed_r[r] = to[r];
+            streamed += M;
+            return STCSP_OK;
+        }
         // (having the kernel write the pinned host arrays itself instead of these copies: search 3.05 -> 4.4 ms, the kernel then holds
         // its wave slots at the speed of the link -- measured again in round 3 with both HIP runtimes, see create())
         HIPCHK(hipMemcpyAsync(h_osrc + streamed, d_osrc.p + streamed, M * sizeof(long long), hipMemcpyDeviceToHost, xs));
@@ -1973,12 +1982,15 @@ struct stcsp_engine {
             fprintf(stderr, "[export] %-22s %.3f ms\n", what, std::chrono::duration<double>(tB - tA).count() * 1e3);
             tA = tB;
         };
-        HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
-        HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
+        const bool quick_try = E && streaming && streamed == E && d_sdeg.n >= n_states && h_begin;
+        if (!quick_try) {  // (the quick path's kernel writes every state's flag: nothing to clear in front of it)
+            HIPCHK(hipMemsetAsync(d_fail.p, 0, n_states, stream));
+            HIPCHK(hipMemsetAsync(d_post.p, 0, 4 * sizeof(uint32_t), stream));
+        }
         const unsigned eb = (unsigned)((E + 255) / 256), sb = (n_states + 255) / 256;
         uint32_t live = 0;
         bool quick_final = false;
-        if (E && streaming && streamed == E && d_sdeg.n >= n_states) {
+        if (quick_try) {
             // the whole log went through the transposition kernels, which counted the out-degrees on their way: the first
             // round of the ok-fixpoint is one pass over the states. Nobody without an out-edge (every shipped example):
             // every logged edge is kept and the streamed arrays are the result.
@@ -1987,11 +1999,10 @@ struct stcsp_engine {
             for (int i = 0; i < 2; i++)
                 if (ev_x_used[i]) HIPCHK(hipStreamWaitEvent(stream, ev_c[i], 0));
             if (ev_k_used) HIPCHK(hipStreamWaitEvent(stream, ev_k, 0));
-            hipLaunchKernelGGL(k_post_mark, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_sdeg.p, d_fail.p, d_post.p);
-            uint32_t changed_local = 0;
-            uint32_t *changed_p = h_begin ? h_begin : &changed_local;  // (pinned scratch of begin(): idle by now)
-            HIPCHK(hipMemcpyAsync(changed_p, d_post.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_fail, d_fail.p, n_states, hipMemcpyDeviceToHost, stream));
+            volatile uint32_t *changed_p = h_begin;  // (pinned scratch of begin(): idle by now, at least the plan header long)
+            *changed_p = 0u;
+            hipLaunchKernelGGL(k_post_mark_host, dim3(sb), dim3(256), 0, stream, n_states, (const uint32_t *)d_sdeg.p, d_fail.p, h_fail, (uint32_t *)h_begin);
+            HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(stream));
             const uint32_t changed = *changed_p;
             quick_final = !changed;
