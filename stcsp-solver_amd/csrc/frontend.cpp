@@ -530,7 +530,7 @@ struct Model {
     // they start from a defined value here (see `not` below).
     Tree *normalise(Tree *node, int &lb, int &ub) {
         if (!node) return nullptr;
-        int myLB = 0, myUB = 1, myLB2 = 0, myUB2 = 1;
+        int llo = 0, lhi = 1, rlo = 0, rhi = 1;
         switch (node->token) {
             case STCSP_T_FIRST: {
                 Tree *r = node->right;
@@ -547,11 +547,11 @@ struct Model {
                     node->right = r->left;
                     return normalise(node, lb, ub);
                 }
-                Tree *nr = normalise(r, myLB, myUB);  // first e -> first e', nested first stripped (:110-121)
+                Tree *nr = normalise(r, llo, lhi);  // first e -> first e', nested first stripped (:110-121)
                 if (nr->token == STCSP_T_FIRST) nr = nr->right;
                 node->right = nr;
-                lb = myLB;
-                ub = myUB;
+                lb = llo;
+                ub = lhi;
                 return node;
             }
             case STCSP_T_NEXT: {
@@ -569,46 +569,46 @@ struct Model {
                 }
                 if (r->token == STCSP_T_FBY)  // next (a fby b) -> b          (:136-141)
                     return normalise(r->right, lb, ub);
-                Tree *nr = normalise(r, myLB, myUB);  //                     (:142-160)
+                Tree *nr = normalise(r, llo, lhi);  //                     (:142-160)
                 Tree *res;
                 if (nr->token == STCSP_T_FIRST) {
                     res = nr;  // the `next` is dropped
                 } else if (nr->token == STCSP_T_CONST || nr->token == STCSP_T_VAR) {
                     node->right = nr;
-                    res = normalise(node, myLB, myUB);
+                    res = normalise(node, llo, lhi);
                 } else {
-                    int x = aux_var(myLB, myUB);
+                    int x = aux_var(llo, lhi);
                     add_var_eq_node(x, nr);
-                    int y = aux_var(myLB, myUB);
+                    int y = aux_var(llo, lhi);
                     add_var_eq_next(y, x);
                     res = arena.variable(y);
                 }
-                lb = myLB;
-                ub = myUB;
+                lb = llo;
+                ub = lhi;
                 return res;
             }
             case STCSP_T_FBY: {  // (:161-188)
                 int y, z;
                 if (node->left->token == STCSP_T_VAR) {
                     y = node->left->var;
-                    myLB = vars[y].lb;
-                    myUB = vars[y].ub;
+                    llo = vars[y].lb;
+                    lhi = vars[y].ub;
                 } else {
-                    Tree *l = normalise(node->left, myLB, myUB);
-                    y = aux_var(myLB, myUB);
+                    Tree *l = normalise(node->left, llo, lhi);
+                    y = aux_var(llo, lhi);
                     add_var_eq_node(y, l);
                 }
                 if (node->right->token == STCSP_T_VAR) {
                     z = node->right->var;
-                    myLB2 = vars[z].lb;
-                    myUB2 = vars[z].ub;
+                    rlo = vars[z].lb;
+                    rhi = vars[z].ub;
                 } else {
-                    Tree *r = normalise(node->right, myLB2, myUB2);
-                    z = aux_var(myLB2, myUB2);
+                    Tree *r = normalise(node->right, rlo, rhi);
+                    z = aux_var(rlo, rhi);
                     add_var_eq_node(z, r);
                 }
-                lb = myLB < myLB2 ? myLB : myLB2;
-                ub = myUB > myUB2 ? myUB : myUB2;
+                lb = llo < rlo ? llo : rlo;
+                ub = lhi > rhi ? lhi : rhi;
                 int x = aux_var(lb, ub);
                 add_first_eq_first(x, y);
                 add_var_eq_next(z, x);
@@ -632,15 +632,15 @@ struct Model {
                 int y;
                 if (l->token == STCSP_T_VAR) {
                     y = l->var;
-                    myLB = vars[y].lb;
-                    myUB = vars[y].ub;
+                    llo = vars[y].lb;
+                    lhi = vars[y].ub;
                 } else {
-                    Tree *nl = normalise(l, myLB, myUB);
-                    y = aux_var(myLB, myUB);
+                    Tree *nl = normalise(l, llo, lhi);
+                    y = aux_var(llo, lhi);
                     add_var_eq_node(y, nl);
                 }
-                lb = myLB;
-                ub = myUB;
+                lb = llo;
+                ub = lhi;
                 int x = aux_var(lb, ub);
                 add_var_eq_at(x, y, node->right->num);
                 return arena.variable(x);
@@ -651,7 +651,7 @@ struct Model {
                 return node;
             case STCSP_T_CONST: lb = ub = node->num; return node;
             case STCSP_T_ARR: {  // (:237-247) bounds = min/max element
-                node->right = normalise(node->right, myLB, myUB);
+                node->right = normalise(node->right, llo, lhi);
                 const std::vector<int> &e = arrays.elements[node->arr];
                 lb = ub = e[0];
                 for (int v : e) {
@@ -663,8 +663,8 @@ struct Model {
             case STCSP_T_UNTIL_CON: {  // (:248-261) both sides forced to identifiers
                 bool left_is_var = node->left->token == STCSP_T_VAR;    // the reference tests the
                 bool right_is_var = node->right->token == STCSP_T_VAR;  // ORIGINAL child tokens
-                Tree *l = normalise(node->left, myLB, myUB);
-                Tree *r = normalise(node->right, myLB2, myUB2);
+                Tree *l = normalise(node->left, llo, lhi);
+                Tree *r = normalise(node->right, rlo, rhi);
                 if (!left_is_var) {
                     int x = aux_var(0, 1);
                     node->left = arena.variable(x);
@@ -682,30 +682,30 @@ struct Model {
         // generic binary / unary branch (:268-327). `not` lands here too: the reference's
         // dedicated `not` arm is dead code (guard typo at :262), so its bounds stay whatever
         // the caller had; here they default to [0,1].
-        Tree *l = normalise(node->left, myLB, myUB);
-        Tree *r = normalise(node->right, myLB2, myUB2);
+        Tree *l = normalise(node->left, llo, lhi);
+        Tree *r = normalise(node->right, rlo, rhi);
         switch (node->token) {
             case STCSP_T_ABS:
                 // (wrapping negation: the bounds of `/` and `%` sub-terms are [INT_MIN, INT_MAX], and -INT_MIN is INT_MIN in
                 // the reference's build as well, solveralgorithm.cpp:316-322)
-                if (myLB2 < 0 && myUB2 < 0) {
-                    lb = neg_wrap(myUB2);
-                    ub = neg_wrap(myLB2);
-                } else if (myLB2 < 0 && myUB2 > 0) {
+                if (rlo < 0 && rhi < 0) {
+                    lb = neg_wrap(rhi);
+                    ub = neg_wrap(rlo);
+                } else if (rlo < 0 && rhi > 0) {
                     lb = 0;
-                    ub = (neg_wrap(myLB2) > myUB2) ? neg_wrap(myLB2) : myUB2;
+                    ub = (neg_wrap(rlo) > rhi) ? neg_wrap(rlo) : rhi;
                 } else {
-                    lb = myLB2;
-                    ub = myUB2;
+                    lb = rlo;
+                    ub = rhi;
                 }
                 break;
             case STCSP_T_IF:
-                lb = myLB2;
-                ub = myUB2;
+                lb = rlo;
+                ub = rhi;
                 break;
             case STCSP_T_THEN:
-                lb = myLB < myLB2 ? myLB : myLB2;
-                ub = myUB > myUB2 ? myUB : myUB2;
+                lb = llo < rlo ? llo : rlo;
+                ub = lhi > rhi ? lhi : rhi;
                 break;
             case STCSP_T_LT_CON: case STCSP_T_GT_CON: case STCSP_T_LE_CON: case STCSP_T_GE_CON:
             case STCSP_T_EQ_CON: case STCSP_T_NE_CON: case STCSP_T_IMPLY_CON:
@@ -716,27 +716,27 @@ struct Model {
                 ub = 1;
                 break;
             case STCSP_T_ADD:
-                lb = (int)((unsigned)myLB + (unsigned)myLB2);
-                ub = (int)((unsigned)myUB + (unsigned)myUB2);
+                lb = (int)((unsigned)llo + (unsigned)rlo);
+                ub = (int)((unsigned)lhi + (unsigned)rhi);
                 break;
             case STCSP_T_SUB:
-                lb = (int)((unsigned)myLB - (unsigned)myUB2);
-                ub = (int)((unsigned)myUB - (unsigned)myLB2);
+                lb = (int)((unsigned)llo - (unsigned)rhi);
+                ub = (int)((unsigned)lhi - (unsigned)rlo);
                 break;
             case STCSP_T_MUL: {
                 auto mul = [](int a, int b) { return (int)((unsigned)a * (unsigned)b); };
-                if (myLB >= 0 && myLB2 >= 0) {
-                    lb = mul(myLB, myLB2);
-                    ub = mul(myUB, myUB2);
-                } else if (myLB >= 0 && myUB2 >= 0 && myLB2 < 0) {
-                    lb = mul(myUB, myLB2);
-                    ub = mul(myUB, myUB2);
-                } else if (myUB >= 0 && myLB < 0 && myLB2 >= 0) {
-                    lb = mul(myLB, myLB2);
-                    ub = mul(myUB, myUB2);
+                if (llo >= 0 && rlo >= 0) {
+                    lb = mul(llo, rlo);
+                    ub = mul(lhi, rhi);
+                } else if (llo >= 0 && rhi >= 0 && rlo < 0) {
+                    lb = mul(lhi, rlo);
+                    ub = mul(lhi, rhi);
+                } else if (lhi >= 0 && llo < 0 && rlo >= 0) {
+                    lb = mul(llo, rlo);
+                    ub = mul(lhi, rhi);
                 } else {
-                    lb = mul(myUB, myUB2);
-                    ub = mul(myLB, myLB2);
+                    lb = mul(lhi, rhi);
+                    ub = mul(llo, rlo);
                 }
                 break;
             }
