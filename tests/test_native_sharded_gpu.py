@@ -126,3 +126,19 @@ def test_cli_shards_writes_the_same_files(stcsp, tmp_path, name, flags):
     assert outs[0][0] == outs[1][0] == outs[2][0]          # "adver1: ..." part
     assert outs[0][1][:3] == outs[1][1][:3] == outs[2][1][:3]  # var con dom
     assert outs[0][2] == outs[1][2] == outs[2][2]
+
+
+def test_native_sharded_resolve_on_the_same_engines(stcsp, golden):
+    """The -t loop of the reference re-solves one model (src/solver.cpp:295-349): the same engines and the same transport group
+    run the sharded search again and again (the table's generation, the plan mirror and the transport's barriers all start over)."""
+    name = "digitinvader3"
+    m = stcsp.Model.from_name(name)
+    engines = [stcsp.Engine(m, rank=r, world=3) for r in range(3)]
+    g = stcsp.LocalGroup(3)
+    gold = golden[name]
+    for _ in range(3):
+        g.solve(engines, budget_rounds=1, share_per_rank=2)
+        h, merged = stcsp.merge_shards([e.export() for e in engines])
+        a = stcsp.Automaton(m, merged).traverse().renumber()
+        assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (gold["states"], gold["edges"], gold["canonical_sha256"])
+        assert sum(e.counters().search_nodes for e in engines) == gold["search"]
