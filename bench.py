@@ -384,12 +384,33 @@ def main():
     # is left with the barriers around the timed region and the final gather. (--python-driver: the loop of sharded.py.)
     native = stepped and not cpu_test and not args.python_driver
     transport = None
+    native_note = None
     if native:
-        uid = torch.zeros(st.RCCL_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(st.rccl_unique_id()), dtype=torch.uint8).to(dev)
-        dist.broadcast(uid, 0)
-        transport = st.RcclTransport(bytes(uid.cpu().tolist()), rank, world, local_rank)
+        # every rank has to end up with the same driver: the ranks agree (all-reduce) on whether the RCCL transport came up
+        # everywhere; if it did not on some rank, all of them take the torch-driven loop and the line says why
+        err = None
+        try:
+            have_id = torch.ones(1, dtype=torch.int32, device=dev)
+            uid = torch.zeros(st.RCCL_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                try:
+                    uid = torch.frombuffer(bytearray(st.rccl_unique_id()), dtype=torch.uint8).to(dev)
+                except Exception as ex:  # noqa: BLE001
+                    err, have_id[0] = ex, 0
+            dist.broadcast(have_id, 0)
+            dist.broadcast(uid, 0)
+            if int(have_id.item()):
+                transport = st.RcclTransport(bytes(uid.cpu().tolist()), rank, world, local_rank)
+        except Exception as ex:  # noqa: BLE001
+            err = err or ex
+        ok = torch.tensor([1 if transport is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            native = False
+            native_note = f"the RCCL transport of libstcsp_rccl.so did not come up on every rank ({type(err).__name__ if err else 'a peer'}: {err}): torch-driven loop"
+            if transport is not None:
+                transport.close()
+                transport = None
 
     def run_native(engine, stats):
         stats.update(st.solve_sharded_native(engine, transport.ptr, **knobs))
@@ -543,6 +564,8 @@ def main():
         if stepped:
             cfg["superstep_driver"] = ("native: stcsp_engine_solve_sharded over the RCCL transport (libstcsp_rccl.so: ncclAllGather for the count table, "
                                        "grouped ncclSend / ncclRecv on the engine's stream)" if native else "python: stcsp-solver_amd/sharded.py over torch.distributed")
+            if native_note:
+                cfg["superstep_driver"] += " -- " + native_note
             if world > 1:
                 cfg["multi_gpu_note"] = "the builder's pool has one GPU per box: every N > 1 figure comes from the driver's run, none was measured while building"
         if cpu_test:
