@@ -1056,6 +1056,33 @@ __global__ void k_pack(const uint32_t *cand_base, uint32_t cand_cap, int CS, con
     }
 }
 
+// ... the same for EVERY owner's outbox in one launch (blockIdx.y = owner): a world of 8 used to cost eight small launches per superstep
+struct PackAllArgs {
+    uint32_t before[64];  // records in front of owner p's part of the packed buffer
+};
+__global__ void k_pack_all(const uint32_t *cand_base, uint32_t cand_cap, int CS, const uint32_t *ctl, int cand0, PackAllArgs a, uint32_t *dst_base) {
+    __shared__ uint32_t pref[R + 1];
+    const int peer = blockIdx.y;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int r = 0; r < R; r++) {
+            pref[r] = acc;
+            acc += ctl[cand0 + (peer * R + r) * CST];
+        }
+        pref[R] = acc;
+    }
+    __syncthreads();
+    const uint32_t *src = cand_base + (size_t)peer * R * cand_cap * CS;
+    uint32_t *dst = dst_base + (size_t)a.before[peer] * CS;
+    const size_t total_words = (size_t)pref[R] * CS;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += (size_t)gridDim.x * blockDim.x) {
+        uint32_t recno = (uint32_t)(w / CS), off = (uint32_t)(w % CS);
+        int r = 0;
+        while (recno >= pref[r + 1]) r++;
+        dst[w] = src[((size_t)r * cand_cap + (recno - pref[r])) * CS + off];
+    }
+}
+
 // ------------------------------------------------------------------ frontier redistribution (sharded runs)
 // k_donate: the top `take[r]` records of every region of ONE frontier segment leave as transfer records
 // (device_types.hpp xfer_stride: constraint set named by tag, dirty seed in a word of its own); the segment's

@@ -807,7 +807,11 @@ struct stcsp_engine {
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         unsigned looks = 0;
         void operator()() {
+#if defined(__x86_64__) || defined(__i386__)
             for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
             if ((++looks & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) std::this_thread::yield();
         }
     };
@@ -1677,17 +1681,24 @@ struct stcsp_engine {
         pack_ptr.assign(opt.world, nullptr);
         pack_count.assign(opt.world, 0);
         size_t before = 0;
+        uint32_t most = 0;
+        PackAllArgs pa{};
         for (int peer = 0; peer < opt.world; peer++) {
             uint32_t total = 0;
             for (int r = 0; r < R; r++) total += h_ctl[L.cand0 + (peer * R + r) * CST];
             uint32_t *dst = d_pack.p + before * ctx.CS;
-            if (total)
+            if (opt.world <= 64) pa.before[peer] = (uint32_t)before;
+            else if (total)  // (more owners than PackAllArgs holds: one launch each)
                 hipLaunchKernelGGL(k_pack, dim3(std::min<uint32_t>(1024, (total * ctx.CS + 255) / 256)), dim3(256), 0, stream,
                                    d_cand.p + (size_t)peer * R * cand_cap * ctx.CS, cand_cap, ctx.CS, d_ctl.p, L.cand0 + peer * R * CST, dst);
             pack_ptr[peer] = dst;
             pack_count[peer] = total;
             before += total;
+            most = std::max(most, total);
         }
+        if (opt.world <= 64 && most)  // every owner's outbox in ONE launch (blockIdx.y = owner)
+            hipLaunchKernelGGL(k_pack_all, dim3(std::min<uint32_t>(1024, (most * ctx.CS + 255) / 256), (unsigned)opt.world), dim3(256), 0, stream,
+                               (const uint32_t *)d_cand.p, cand_cap, ctx.CS, (const uint32_t *)d_ctl.p, L.cand0, pa, d_pack.p);
         HIPCHK(hipGetLastError());
         if (sync) HIPCHK(hipStreamSynchronize(stream));  // (a driver that moves the records on another stream; the native loop's transports are ordered on this one)
         packed = true;
