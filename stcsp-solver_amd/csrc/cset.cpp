@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -197,6 +198,7 @@ int SetManager::init(const stcsp_problem *p, bool sharded_tags) {
         return STCSP_E_INVALID;
     }
     sharded = sharded_tags;
+    if (const char *ev = getenv("STCSP_SPLIT_WIDE")) split_mode = atoi(ev);  // tuning / A-B: 0 keeps wide conditionals interpreted
     N = p->n_vars;
     K = p->prefix_k;
     lb.assign(p->var_lb, p->var_lb + N);
@@ -701,6 +703,74 @@ void SetManager::build_entry(const HostCon &c, TableEntry &e) {
     e.n_forbidden = product - allowed <= kFewForbidden ? (int32_t)(product - allowed) : -1;
 }
 
+// ------------------------------------------------------------------ wide constraints with conditionals
+// A point constraint over more variables than a tuple bitmap can hold (juggling `_nosym`: A == if B0 eq 1 then next B0 else if
+// B1 eq 1 then ... over 13 variables of 7 values) would be interpreted tuple by tuple. Evaluation is pure and total here (no
+// array look-ups in the tree: nothing clears `valid`; x / 0 is defined), so a conditional can be lifted out of ANY context:
+//     T[if c then t else e]  ==  if c then T[t] else T[e]
+// and as a constraint (non-zero = satisfied) that is the conjunction of (if c then T[t] else 1) and (if c then 1 else T[e]).
+// Repeated until every branch fits a bitmap, the constraint becomes a handful of guarded branches, each over the variables of
+// its guards and ONE branch body -- tabulated like any other constraint. Only the compiled program changes: the set keeps the
+// constraint as written (identity, translation, serialisation), and the conjunction has the same solutions, so leaves are
+// checked exactly as before; propagation on the branches is GAC per branch (sound; the search stays complete).
+static Tree *clone_tree(const Tree *t, TreeArena &a, const Tree *hole = nullptr, const Tree *fill = nullptr) {
+    if (!t) return nullptr;
+    if (t == hole) return clone_tree(fill, a);
+    Tree *l = clone_tree(t->left, a, hole, fill);
+    Tree *r = clone_tree(t->right, a, hole, fill);
+    return a.make(t->token, t->num, t->var, t->arr, l, r);
+}
+static const Tree *first_if(const Tree *t) {  // pre-order: the outermost conditional first
+    if (!t) return nullptr;
+    if (t->token == STCSP_T_IF && t->right && t->right->token == STCSP_T_THEN) return t;
+    if (const Tree *l = first_if(t->left)) return l;
+    return first_if(t->right);
+}
+
+bool SetManager::split_wide(const Tree *body, std::vector<Guard> &guards, long long limit, std::vector<Tree *> &out, int &budget) {
+    std::vector<int> scope;
+    for (const Guard &g : guards) collect_scope(g.cond, scope);
+    collect_scope(body, scope);
+    long long product = 1;
+    for (int v : scope) product = std::min<long long>(product * ((long long)ub[v] - lb[v] + 1), limit + 1);
+    const Tree *f = product <= split_target ? nullptr : first_if(body);
+    if (!f) {
+        if (product > limit) return false;
+        Tree *t = clone_tree(body, piece_arena);
+        for (size_t k = guards.size(); k-- > 0;) {
+            Tree *one = piece_arena.constant(1);
+            Tree *th = piece_arena.make(STCSP_T_THEN, 0, -1, -1, guards[k].taken ? t : one, guards[k].taken ? one : t);
+            t = piece_arena.make(STCSP_T_IF, 0, -1, -1, clone_tree(guards[k].cond, piece_arena), th);
+        }
+        out.push_back(t);
+        return true;
+    }
+    if (--budget < 0) return false;
+    TreeArena scratch;  // the two bodies with the conditional replaced by one of its branches
+    const Tree *bt = clone_tree(body, scratch, f, f->right->left);
+    const Tree *be = clone_tree(body, scratch, f, f->right->right);
+    guards.push_back(Guard{f->left, true});
+    bool ok = split_wide(bt, guards, limit, out, budget);
+    guards.back().taken = false;
+    ok = ok && split_wide(be, guards, limit, out, budget);
+    guards.pop_back();
+    return ok;
+}
+
+const std::vector<Tree *> &SetManager::pieces_of(const HostCon &c, const std::vector<int32_t> &key) {
+    auto it = piece_cache.find(key);
+    if (it != piece_cache.end()) return it->second;
+    std::vector<Tree *> out;
+    if (split_mode > 0 && c.type == CT_POINT && !tree_has_arr(c.root) && first_if(c.root)) {
+        std::vector<Guard> guards;
+        int budget = 64;  // conditionals lifted per constraint (each adds one branch)
+        const long long limit = device_tabulation ? kBitmapMaxBitsDevice : kBitmapMaxBits;
+        split_target = split_mode >= 2 ? 0 : limit;
+        if (!split_wide(c.root, guards, limit, out, budget) || out.size() < 2) out.clear();
+    }
+    return piece_cache.emplace(key, std::move(out)).first->second;
+}
+
 void SetManager::store_tabulated(const std::vector<int32_t> &key, const uint32_t *words, size_t n, long long product) {
     auto it = table_cache.find(key);
     if (it == table_cache.end() || it->second.words.size() != n) return;
@@ -778,8 +848,43 @@ int SetManager::compile(FlatProgram &out) {
         std::vector<ItemDesc> small_items, wave_items;
         std::vector<uint32_t> nxt((size_t)N * K * 2, 0u);  // eager X == next Y partners per block word (SetDesc::next_off)
         bool any_next = false;
-        for (size_t ci = 0; ci < s.cons.size(); ci++) {
-            HostCon &c = s.cons[ci];
+        // the constraints the PROGRAM propagates: the set's own, except that a conditional constraint too wide for a bitmap
+        // is replaced by its guarded branches (split_wide)
+        std::vector<HostCon> pcons;
+        for (const HostCon &c0 : s.cons) {
+            bool split = false;
+            if (split_mode > 0 && c0.type == CT_POINT && !c0.scope.empty()) {
+                std::vector<int32_t> key;
+                serialise_tree(c0.root, key);
+                auto ce = table_cache.find(key);
+                if (ce == table_cache.end()) {
+                    ce = table_cache.emplace(key, TableEntry()).first;
+                    build_entry(c0, ce->second);
+                }
+                if (!ce->second.is_small && (split_mode >= 2 || !ce->second.bitmap)) {
+                    for (Tree *piece : pieces_of(c0, key)) {
+                        HostCon pc;
+                        pc.root = piece;
+                        pc.type = CT_POINT;
+                        pc.has_first = c0.has_first;
+                        collect_scope(piece, pc.scope);
+                        pcons.push_back(pc);
+                        split = true;
+                    }
+                }
+            }
+            if (!split) pcons.push_back(c0);
+        }
+        sd.ncons = (int32_t)pcons.size();
+        sd.cw = std::max(1, (sd.ncons + 31) / 32);
+        if (sd.cw > 64) {
+            error = "more than 2048 constraints in one set";
+            return STCSP_E_UNSUPPORTED;
+        }
+        if (sd.cw > out.max_cw) out.max_cw = sd.cw;
+        out.varcons.resize((size_t)sd.varcons_off + (size_t)N * sd.cw, 0u);
+        for (size_t ci = 0; ci < pcons.size(); ci++) {
+            HostCon &c = pcons[ci];
             ConDesc cd{};
             cd.n_forbidden = -1;
             cd.type = c.type;
@@ -960,17 +1065,25 @@ int SetManager::compile(FlatProgram &out) {
         out.items.insert(out.items.end(), small_items.begin(), small_items.end());
         out.items.insert(out.items.end(), wave_items.begin(), wave_items.end());
         sd.itemrows_off = (int32_t)out.itemrows.size();
-        out.itemrows.resize(out.itemrows.size() + (size_t)N * K * sd.iw, 0u);
+        // rows [0, N*K): the items that read block word (p, v); row N*K: the items with work in a FRESH state under the same set
+        // (dirty seed N*K + 1, dev_propagate.hpp process_node) -- those that read the new time point K-1, until checks (their
+        // expire bits change with the state) and constraints with a `first` (enforced at point 0 only, which they now see for
+        // the first time); every other item saw the same domains one point later in the leaf the state comes from
+        out.itemrows.resize(out.itemrows.size() + ((size_t)N * K + 1) * sd.iw, 0u);
         for (int i = 0; i < sd.nitems; i++) {
             const ItemDesc &it = out.items[sd.item_begin + i];
             auto mark = [&](int word) { out.itemrows[sd.itemrows_off + (size_t)word * sd.iw + i / 32] |= 1u << (i % 32); };
+            bool fresh;
             if (it.type == IT_NEXT || it.type == IT_UNTIL) {
                 mark(it.idx[0]);
                 mark(it.idx[1]);
+                fresh = it.type == IT_UNTIL || it.point + 1 == K - 1;
             } else {
                 const ConDesc &cd = out.cons[it.con];
                 for (int j = 0; j < cd.scope_len; j++) mark(it.point * N + out.scope[cd.scope_off + j]);
+                fresh = it.point == K - 1 || cd.npoints < K;
             }
+            if (fresh) mark(N * K);
         }
         out.sets.push_back(sd);
     }

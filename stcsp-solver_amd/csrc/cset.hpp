@@ -96,6 +96,13 @@ public:
     std::multimap<uint64_t, int> set_by_hash;  // content hash -> set index (constraintQueueEq decides; the hash only finds candidates)
     std::string error;
     std::map<std::vector<int32_t>, TableEntry> table_cache;
+    // A point constraint too wide for a tuple bitmap whose tree holds an `if` is replaced -- in the compiled PROGRAM only, the set's
+    // identity keeps the constraint as written -- by the conjunction of its branches (split_wide): serialised tree -> branch trees.
+    // An empty entry: the constraint stays as it is (interpreted).
+    std::map<std::vector<int32_t>, std::vector<Tree *>> piece_cache;
+    TreeArena piece_arena;
+    int split_mode = 1;            // 0: never; 1: constraints no bitmap can hold; 2: every conditional constraint that is not lane-revised
+    long long split_target = 0;    // a branch at most this big is not split further (set by compile)
     // Bitset words per (variable, time point): 1 while every variable has at most 32 values, else 2 (<= 64) or 4 (<= 128).
     // Programs compiled for W > 1 have no lane-revised items and no eager arcs: X == next Y, until and point constraints are
     // all wavefront-revised items (device: dev_wide.hpp). 0: some variable is wider than 128 values (no bitset path).
@@ -126,6 +133,12 @@ private:
     Tree *translate_first(HostSet &dst, const Tree *t, const std::map<int, int> &vals);
     int eval_tree(const Tree *t, const std::vector<int> &scope, const int *vals, bool &valid) const;
     void build_entry(const HostCon &c, TableEntry &e);
+    struct Guard {
+        const Tree *cond;
+        bool taken;
+    };
+    bool split_wide(const Tree *body, std::vector<Guard> &guards, long long limit, std::vector<Tree *> &out, int &budget);
+    const std::vector<Tree *> &pieces_of(const HostCon &c, const std::vector<int32_t> &key);
     int compile_expr(const Tree *t, const std::vector<int> &scope, bool guards, std::vector<int32_t> &code, int &depth,
                      int &max_depth, int &mask_depth);
 };

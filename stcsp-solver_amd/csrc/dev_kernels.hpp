@@ -33,9 +33,22 @@ __device__ __forceinline__ Ctx ctx_from(const uint32_t (&hot)[2]) {
 // accesses are LDS instructions whatever the compiler can or cannot infer about a pointer into it
 extern __shared__ __attribute__((aligned(16))) int stcsp_lds[];
 
+// Which parked sibling a slot goes on with when its path has ended. In a DRY round (fewer slots than resident wavefronts: the
+// round lasts as long as its longest slot) of the general kernels the OLDEST one: the root of the biggest subtree still waiting,
+// the one the rest of the search is most likely to wait for (juggling `_nosym` 10-25 % faster). Otherwise the youngest
+// (depth-first: the stack stays short, fewer children travel through the frontier -- digitinvader9's wide rounds lose 7 % with
+// oldest-first; the LITE kernels' chains are four expansions long).
+#ifndef STCSP_SIB_OLDEST
+#define STCSP_SIB_OLDEST 1
+#endif
+// A new state under the constraint set of the state it comes from starts with the dirty seed N*K + 1 ("fresh"): only the items
+// that read the fresh time point are dirty (process_node). 0: every item, as before round 4.
+#ifndef STCSP_FRESH_SEED
+#define STCSP_FRESH_SEED 1
+#endif
 template <int DR, int L, bool CS, bool LITE, int W = 1>
 __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const Img<L> &P, int gw, int lane, int *lds_vals, int *lds_stk, int *ldom,
-                            int sib_off, WaveEnv<DR> &env) {
+                            int sib_off, WaveEnv<DR> &env, bool dry = false) {
     const Ctx c0 = ctx_from(hot);
     const Ctx &c = c0;
     const int r = gw % R, i = gw / R;
@@ -175,7 +188,7 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
             return;                                                                        \
         }                                                                                  \
         sd--;                                                                              \
-        const int sib = sib_off + sd * c.NS;                                               \
+        const int sib = sib_off + (STCSP_SIB_OLDEST && !LITE && dry ? 0 : sd * c.NS);      \
         hd.h0 = rflu((uint32_t)stcsp_lds[sib]);                                            \
         hd.h1 = rflu((uint32_t)stcsp_lds[sib + 1]);                                        \
         const uint32_t sw2 = rflu((uint32_t)stcsp_lds[sib + 2]);                           \
@@ -185,6 +198,13 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         _Pragma("unroll") for (int q = 0; q < DR; q++) {                                   \
             const int idx = q * 64 + lane;                                                 \
             dom.r[q] = idx < c.NK ? (uint32_t)stcsp_lds[sib + 4 + idx] : 0u;               \
+        }                                                                                  \
+        if (STCSP_SIB_OLDEST && !LITE && dry) { /* the younger ones move down (reads run ahead of the writes) */ \
+            for (int w = lane; w < sd * c.NS; w += 64) {                                   \
+                const int x = stcsp_lds[sib_off + c.NS + w];                               \
+                stcsp_lds[sib_off + w] = x;                                                \
+            }                                                                              \
+            STCSP_REJOIN();                                                                \
         }                                                                                  \
         continue;                                                                          \
     }
@@ -291,7 +311,8 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         if (!co.is_new) STCSP_PATH_END();
         env.n_new++;
         if (last) {
-            env.err = max(env.err, emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk));
+            env.err = max(env.err, emit_state_node<DR>(c, lane, ro, a.out_base, a.out_cap, a.parity, co, lo.new_expire, lo.nblk,
+                                                       (STCSP_FRESH_SEED && W == 1 && co.set == hd.set) ? (uint32_t)(c.N * c.K + 1) : 0u));
             uint32_t fpos;
             flush_siblings(c, 0u, fpos);
             return;
@@ -300,8 +321,10 @@ __device__ void expand_node(const uint32_t (&hot)[2], const ExpandArgs &a, const
         const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
         hd.h0 = (uint32_t)gid;
         hd.h1 = (uint32_t)(gid >> 32);
+        // (a state that runs under the SAME constraint set as the one it comes from starts with the fresh point's items dirty only:
+        // process_node, kSeedFresh)
+        hd.seed = (STCSP_FRESH_SEED && W == 1 && co.set == hd.set) ? (uint32_t)(c.N * c.K + 1) : 0u;
         hd.set = co.set;
-        hd.seed = 0;
         hd.expire = lo.new_expire;
 #pragma unroll
         for (int q = 0; q < DR; q++) dom.r[q] = lo.nblk[q];
@@ -766,7 +789,7 @@ __global__ __launch_bounds__(BIG ? STCSP_BIG_WAVES * 64 : 256, BIG ? 1 : (STCSP_
         for (int gw = blockIdx.x * wpb + wib; gw < n_slots;) {
             unsigned ticket = 0;
             if (lane == 0) ticket = atomicAdd(cursor, 1u);
-            expand_node<DR, L, CS, LITE, W>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env);
+            expand_node<DR, L, CS, LITE, W>(hot, a, P, gw, lane, lds_vals, lds_stk, ldom, sib_off, env, n_slots <= total_waves);
             gw = total_waves + (int)rflu(ticket) * ncur + cur;
         }
     }
@@ -983,7 +1006,7 @@ __device__ CommitOut table_commit(const Ctx &c, int lane, int ro, uint32_t kw, u
 // new state: open its first search node in the round's output segment
 template <int DR>
 __device__ unsigned emit_state_node(const Ctx &c, int lane, int ro, uint32_t *out_base, uint32_t out_cap, int parity,
-                                    const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR]) {
+                                    const CommitOut &co, uint32_t expire, const uint32_t (&blk)[DR], uint32_t seed) {
     const CtlLayout L(c.world);
     uint32_t np = 0;
     if (lane == 0) np = atomicAdd(&c.ctl[L.out(parity, ro)], 1u);
@@ -991,7 +1014,7 @@ __device__ unsigned emit_state_node(const Ctx &c, int lane, int ro, uint32_t *ou
     if (np + 1 > out_cap) return ERR_OUT_OVERFLOW;
     uint32_t *dst = out_base + ((size_t)ro * out_cap + np) * c.NS;
     const unsigned long long gid = ((unsigned long long)c.rank << STCSP_GID_SHIFT) | co.idx;
-    if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? (uint32_t)co.set : expire));
+    if (lane < 4) dst[lane] = lane == 0 ? (uint32_t)gid : (lane == 1 ? (uint32_t)(gid >> 32) : (lane == 2 ? ((uint32_t)co.set | seed << kSetBits) : expire));
 #pragma unroll
     for (int q = 0; q < DR; q++) {
         int k = q * 64 + lane;
@@ -1028,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_commit(Ctx c, CommitArgs a) {
     unsigned err = co.ok ? 0u : co.err;
     if (co.ok && co.is_new) {
         if (lane == 0) add_stats(c, (int)(gw & 0x7fffffff), ST_NEWSTATES, 1);
-        err = emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk);
+        err = emit_state_node<DR>(c, lane, ro, c.arena + p->out_base, p->out_cap, p->parity, co, expire, blk, 0u);
         if (err == ERR_OUT_OVERFLOW) err = ERR_COMMIT_OUT_OVERFLOW;
     }
     if (err && lane == 0) atomicMax(&c.ctl[CtlLayout(c.world).misc0 + MISC_ERROR * CST], (uint32_t)err);

@@ -396,3 +396,38 @@ def test_engine_merges_sets_that_differ_only_in_the_array(stcsp, RefOracle):
     a, _ = finish(e, r)
     assert a.canonical() == ao.canonical()
     assert r.counters.translation_stops == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_engine_wide_conditionals_as_guarded_branches(stcsp, golden, monkeypatch, mode):
+    """cset.cpp split_wide: a conditional constraint too wide for a tuple bitmap (juggling `_nosym`: 11 and 13 variables of 6-7
+    values) runs as the conjunction of its guarded branches in the compiled program -- same solutions, so the same automaton as the
+    reference, and the same search tree wherever the reference never fails. STCSP_SPLIT_WIDE=0 keeps the constraint interpreted,
+    2 also splits every conditional constraint that has a bitmap (digitinvader's `next D == if ...`)."""
+    monkeypatch.setenv("STCSP_SPLIT_WIDE", mode)
+    for name in ["juggling_b5_f5_nosym", "juggling_b6_f6_nosym", "digitinvader3", "juggling_b4_f5"]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m)
+        r = e.solve()
+        a, _ = finish(e, r)
+        g = golden[name]
+        assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (g["states"], g["edges"], g["canonical_sha256"]), name
+        assert r.counters.dominance == g["dom"], name
+        assert r.counters.search_nodes == g["search"] or g["fail"] > 0, name
+
+
+@pytest.mark.gpu
+def test_engine_fresh_states_start_with_the_new_point_dirty_only(stcsp, golden):
+    """A state opened under the constraint set of the state it comes from starts with the dirty seed N*K + 1: only the items that
+    read the new time point (and until / `first` items) are revised at its first node (dev_propagate.hpp process_node). The
+    fixpoint is the same as with every item dirty: same search tree as the reference on models that open tens of thousands of
+    states under one set, with chains (states entered inside a slot) and with 64-node batches (states entered from the frontier)."""
+    for name, kw in [("partialorder_12", {}), ("digitinvader6", {}), ("digitinvader4", {"batch_nodes": 64}), ("juggling_b5_f6", {"batch_nodes": 64})]:
+        m = stcsp.Model.from_name(name)
+        e = stcsp.Engine(m, **kw)
+        r = e.solve()
+        a, _ = finish(e, r)
+        g = golden[name]
+        assert a.canonical_sha256() == g["canonical_sha256"], name
+        assert (r.counters.search_nodes, r.n_states, r.counters.fails) == (g["search"], g["node"], 0), name

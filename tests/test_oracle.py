@@ -217,3 +217,21 @@ def test_sets_that_differ_only_in_the_array_are_one_set(stcsp, oracle_lib, RefOr
     assert a.canonical() == ao.canonical()
     # the merged set really is the one over B (z = 1 on the self-loops of BOTH one-constraint states), as in the reference
     assert "E 2 2 0 1 1 0 1" in ao.canonical() and "E 3 3 1 0 1 1 0" in ao.canonical()
+
+
+def test_wide_conditional_constraints_split_into_guarded_branches(stcsp, FrontierModel, golden, monkeypatch):
+    """cset.cpp split_wide on the CPU (the frontier model runs the product's compiler): juggling_b4_f5_nosym's 9-variable
+    `A == if B0 eq 1 then next B0 else if ...` (6^9 tuples: more than the host tabulates) becomes five guarded branches of at most
+    6^6 tuples. Same automaton as the reference either way, a fraction of the tuple evaluations with the branches."""
+    name = "juggling_b4_f5_nosym"
+    g = golden[name]
+    evals = {}
+    for mode in ["0", "1"]:
+        monkeypatch.setenv("STCSP_SPLIT_WIDE", mode)
+        f = FrontierModel(stcsp.Model.from_name(name))
+        r = f.solve()
+        a, _ = finish(f, r)
+        assert (a.n_live_states, a.n_live_edges, a.canonical_sha256()) == (g["states"], g["edges"], g["canonical_sha256"]), mode
+        assert r.counters.dominance == g["dom"]
+        evals[mode] = r.counters.evaluations
+    assert evals["1"] * 3 < evals["0"]
