@@ -12,15 +12,15 @@ namespace dev {
 constexpr int R = kRegions;
 constexpr int CST = kCursorStride;
 constexpr int kStatSlots = 64;
-constexpr int kStatWords = 44;
+constexpr int kStatWords = 48;
 enum { ST_NODES = 0, ST_FAILS, ST_LEAVES, ST_REVS, ST_EVALS, ST_REQUEUE, ST_NEWSTATES, ST_WAVEREVS, ST_SWEEPS, ST_SKIPPED,  // (the first kMirrorCounters: Progress::counters)
        ST_CYC_LOAD, ST_CYC_SWEEP, ST_CYC_WAVE, ST_CYC_CLASSIFY, ST_CYC_COMMIT, ST_CYC_TOTAL,
        ST_BATCHES, ST_BATCH_ITEMS, ST_CYC_BATCH, ST_BATCH_REFUSED, ST_CYC_BATCH_AB, ST_CYC_BATCH_DE, ST_BATCH_TUPLES,  // revise_batch (phases build)
        ST_CYC_STAGE, ST_BLOCKS, ST_CYC_FINAL, ST_ROUNDS_FINAL, ST_CYC_BLOCK,
        ST_CYC_RV_SETUP, ST_CYC_RV_LOOP, ST_CYC_RV_WB, ST_CYC_CLOSE, ST_CYC_LEAF, ST_RV_BLOCKS, ST_RV_OPEN, ST_RV_LANES,
        ST_CYC_RV_DIGITS, ST_CYC_RV_EVAL_BITMAP, ST_CYC_RV_EVAL_CODE, ST_CYC_RV_SUPPORT, ST_RV_BLOCKS_CODE,
-       ST_ROOTS, ST_CYC_ROOT_SWEEP, ST_CYC_ROOT_WAVE };  // first nodes of states (phases build)
-static_assert(ST_CYC_ROOT_WAVE < kStatWords, "statistics row");
+       ST_ROOTS, ST_CYC_ROOT_SWEEP, ST_CYC_ROOT_WAVE, ST_ROOT_BATCHES, ST_ROOT_CYC_BATCH, ST_ROOT_RV_BLOCKS, ST_ROOT_REFUSED };  // first nodes of states (phases build)
+static_assert(ST_ROOT_REFUSED < kStatWords, "statistics row");
 // per-wavefront LDS words behind the block copy: [0] rows examined by the current node's sweeps, [1 + ST_x]
 // the wavefront's work counters of this launch (flushed to the global statistics once per launch)
 constexpr int kLdsStatWords = 12;

@@ -1519,6 +1519,15 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         add_stats(c, gw, ST_CYC_BATCH, ws.cyc_batch);
         add_stats(c, gw, ST_CYC_BATCH_AB, ws.cyc_batch_ab);
         add_stats(c, gw, ST_CYC_BATCH_DE, ws.cyc_batch_de);
+        if (seed == 0 || seed == (uint32_t)(c.N * c.K + 1)) {  // the first node of a state
+            add_stats(c, gw, ST_ROOTS, 1);
+            add_stats(c, gw, ST_CYC_ROOT_SWEEP, ws.cyc_sweep);
+            add_stats(c, gw, ST_CYC_ROOT_WAVE, ws.cyc_wave);
+            add_stats(c, gw, ST_ROOT_BATCHES, ws.batches);
+            add_stats(c, gw, ST_ROOT_CYC_BATCH, ws.cyc_batch);
+            add_stats(c, gw, ST_ROOT_RV_BLOCKS, ws.rv_blocks);
+            add_stats(c, gw, ST_ROOT_REFUSED, ws.batch_refused);
+        }
         if (seed == 0 || seed == (uint32_t)(c.N * c.K + 1)) {
             add_stats(c, gw, ST_ROOTS, 1);
             add_stats(c, gw, ST_CYC_ROOT_SWEEP, ws.cyc_sweep);

@@ -1579,7 +1579,9 @@ struct stcsp_engine {
                     (double)tot[ST_CYC_TOTAL] / tot[ST_NODES], (unsigned long long)tot[ST_NODES]);
         if (tot[ST_ROOTS])
             fprintf(stderr, "[phases] first nodes of states: %llu, sweeps %.0f + wavefront revisions %.0f cycles each (all nodes: %.0f + %.0f)\n", (unsigned long long)tot[ST_ROOTS],
-                    (double)tot[ST_CYC_ROOT_SWEEP] / tot[ST_ROOTS], (double)tot[ST_CYC_ROOT_WAVE] / tot[ST_ROOTS], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES], (double)tot[ST_CYC_WAVE] / tot[ST_NODES]);
+                    (double)tot[ST_CYC_ROOT_SWEEP] / tot[ST_ROOTS], (double)tot[ST_CYC_ROOT_WAVE] / tot[ST_ROOTS], (double)tot[ST_CYC_SWEEP] / tot[ST_NODES], (double)tot[ST_CYC_WAVE] / tot[ST_NODES]),
+            fprintf(stderr, "[phases] ... per first node: %.2f batches (%.0f cycles in them), %.2f refused scans, %.1f odometer steps\n",
+                    (double)tot[ST_ROOT_BATCHES] / tot[ST_ROOTS], (double)tot[ST_ROOT_CYC_BATCH] / tot[ST_ROOTS], (double)tot[ST_ROOT_REFUSED] / tot[ST_ROOTS], (double)tot[ST_ROOT_RV_BLOCKS] / tot[ST_ROOTS]);
         if (tot[ST_WAVEREVS])
             fprintf(stderr, "[phases] per wavefront revision (completed ones): setup %.0f, enumeration %.0f, write-back %.0f cycles; %.2f revisions per node\n",
                     (double)tot[ST_CYC_RV_SETUP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_LOOP] / tot[ST_WAVEREVS], (double)tot[ST_CYC_RV_WB] / tot[ST_WAVEREVS],
