@@ -784,6 +784,8 @@ void SetManager::store_tabulated(const std::vector<int32_t> &key, const uint32_t
 
 int SetManager::compile(FlatProgram &out) {
     out = FlatProgram();
+    n_split = 0;
+    n_wide_conditional = 0;
     struct Placed {  // where a cached table sits in THIS program image
         int32_t off, stride_off;
     };
@@ -856,12 +858,19 @@ int SetManager::compile(FlatProgram &out) {
             if (split_mode > 0 && c0.type == CT_POINT && !c0.scope.empty()) {
                 std::vector<int32_t> key;
                 serialise_tree(c0.root, key);
-                auto ce = table_cache.find(key);
-                if (ce == table_cache.end()) {
-                    ce = table_cache.emplace(key, TableEntry()).first;
-                    build_entry(c0, ce->second);
+                long long product = 1;
+                for (int v : c0.scope) product = std::min<long long>(product * ((long long)ub[v] - lb[v] + 1), kBitmapMaxBitsDevice + 1);
+                if (product > kWideConditional && first_if(c0.root)) n_wide_conditional++;
+                bool try_split = product > (device_tabulation ? kBitmapMaxBitsDevice : kBitmapMaxBits);  // (no bitmap can hold it)
+                if (!try_split && split_mode >= 2) {
+                    auto ce = table_cache.find(key);
+                    if (ce == table_cache.end()) {
+                        ce = table_cache.emplace(key, TableEntry()).first;
+                        build_entry(c0, ce->second);
+                    }
+                    try_split = !ce->second.is_small;
                 }
-                if (!ce->second.is_small && (split_mode >= 2 || !ce->second.bitmap)) {
+                if (try_split) {
                     for (Tree *piece : pieces_of(c0, key)) {
                         HostCon pc;
                         pc.root = piece;
@@ -874,6 +883,7 @@ int SetManager::compile(FlatProgram &out) {
                 }
             }
             if (!split) pcons.push_back(c0);
+            n_split += split;
         }
         sd.ncons = (int32_t)pcons.size();
         sd.cw = std::max(1, (sd.ncons + 31) / 32);

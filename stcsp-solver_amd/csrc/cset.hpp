@@ -101,7 +101,9 @@ public:
     // An empty entry: the constraint stays as it is (interpreted).
     std::map<std::vector<int32_t>, std::vector<Tree *>> piece_cache;
     TreeArena piece_arena;
-    int split_mode = 1;            // 0: never; 1: constraints no bitmap can hold; 2: every conditional constraint that is not lane-revised
+    int split_mode = 1;            // 0: never; 1: conditional constraints no bitmap can hold; 2: every conditional constraint that is not lane-revised
+    int n_split = 0;               // constraints the last compile() replaced by their guarded branches
+    int n_wide_conditional = 0;    // ... and conditional constraints over more than kWideConditional tuples it saw, split or not (engine: chain policy)
     long long split_target = 0;    // a branch at most this big is not split further (set by compile)
     // Bitset words per (variable, time point): 1 while every variable has at most 32 values, else 2 (<= 64) or 4 (<= 128).
     // Programs compiled for W > 1 have no lane-revised items and no eager arcs: X == next Y, until and point constraints are

@@ -103,7 +103,7 @@ struct stcsp_engine {
     // nodes, else chain_big; a slot stops chaining after chain_heavy cycles in one launch (measured
     // optimum 300-500 k on digitinvader5/7/9, flat on partialorder). chain_small: 16 (round 3: 8) under the general kernels
     // (expensive nodes: fewer, longer rounds -- digitinvader9 27.2 -> 23.4 ms), 4 under the LITE ones
-    // (partialorder_12/14/16 lose 3-10 % with 8), 2 when a constraint is interpreted (the juggling _nosym instances: a few thousand
+    // (partialorder_12/14/16 lose 3-10 % with 8), 1 when the program has a conditional constraint over more than 2^20 tuples (a case analysis over a dozen variables: the juggling family, round 4: a few hundred to a few thousand expensive nodes in a search 15 node levels deep -- a slot that walks a subtree depth-first holds its round, and every idle wavefront, for the whole walk: level-synchronous rounds are twice as fast, juggling_b6_f6_nosym 1.9 -> 0.9 ms; digitinvader, 260 levels deep with a dear first node per state, is twice as SLOW that way), 2 when a constraint is interpreted (round 3's juggling _nosym: a few thousand
     // uniformly expensive nodes, longer chains only serialise them: juggling_b6_f6_nosym 2.5 -> 1.8 ms); chain_big 4 since the sibling stack (2 before: partialorder_18 81 -> 74.5 ms,
     // synthetic 64 x 32 71 -> 76 M nodes/s; 6 and 8 are slower again). STCSP_CHAIN_SMALL / _BIG / _THRESH / _HEAVY override.
     bool chain_small_auto = true;
@@ -128,6 +128,7 @@ struct stcsp_engine {
     int prefix_need = 0;          // image words that must be staged for the L = 2 kernels (0: not applicable)
     bool prefix_complete = false; // ... and they are: general program, everything but cons / tables in the staged prefix
     bool interpreted = false;     // some wavefront-revised constraint has no tuple bitmap (postfix interpreter: uniformly expensive nodes)
+    bool wide_conditional = false;  // some conditional constraint spans more than kWideConditional tuples (the juggling family's `A == if B0 eq 1 then next B0 else if ...`)
     bool host_view_fresh = false;  // h_ctl / h_plan were read after the last device work (expand_local -> commit)
     bool packed = false;      // the outboxes of the last expand_local are packed (pack_ptr / pack_count valid)
     int64_t step_max_rounds = 0, step_min_open = 0;  // expand_local budget (set_expand_budget): 0 = run the frontier dry
@@ -242,6 +243,7 @@ struct stcsp_engine {
         // bytecode interpreter, their LDS scratch and ~25 VGPRs) is compiled out: more resident wavefronts.
         lite = true;
         interpreted = false;
+        wide_conditional = mgr.n_wide_conditional > 0;
         for (const SetDesc &sd : prog.sets)
             for (int i = sd.nsmall; i < sd.nitems; i++) {
                 const ConDesc &cd = prog.cons[prog.items[sd.item_begin + i].con];
@@ -675,7 +677,7 @@ struct stcsp_engine {
         // chain, so a region of an owner's outbox receives up to chain x max-take candidates per launch; the planner takes no
         // more nodes per region than the outboxes have room for (plan_next), so their size is independent of the batch: room
         // for 4,096 nodes per region and launch (world 8: 3.4 GB at 100-word records).
-        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 16);  // (what begin() will plan with: the outboxes are sized for it)
+        if (chain_small_auto) chain_small = lite ? 4 : (wide_conditional ? 1 : (interpreted ? 2 : 16));  // (what begin() will plan with: the outboxes are sized for it)
         cand_cap = (uint32_t)(sharded ? std::max(std::max(8, std::max(chain_small, chain_big)) * std::min(chunk_r, 4096), 4096) : 64);
         if (const char *ev = getenv("STCSP_CAND_CAP")) if (sharded && atoi(ev) > 0) cand_cap = (uint32_t)std::max(atoi(ev), 2 * std::max(chain_small, chain_big));  // tests: outboxes that fill up
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
@@ -1009,7 +1011,7 @@ struct stcsp_engine {
         h_plan->chunk_r = chunk_r;
         // (general kernels: 16 since round 4 -- the time cap chain_heavy is what ends a slot there, the count only has to stay out of
         // its way: digitinvader9 18.8 -> 17.9 ms, digitinvader7 10.1 -> 9.6 with 16 instead of 8; 24 the same; tools/env_sweep.py)
-        if (chain_small_auto) chain_small = lite ? 4 : (interpreted ? 2 : 16);
+        if (chain_small_auto) chain_small = lite ? 4 : (wide_conditional ? 1 : (interpreted ? 2 : 16));
         h_plan->chain_small = chain_small;
         h_plan->chain_big = chain_big;
         h_plan->chain_thresh = chain_thresh;
