@@ -198,6 +198,7 @@ int SetManager::init(const stcsp_problem *p, bool sharded_tags) {
         return STCSP_E_INVALID;
     }
     sharded = sharded_tags;
+    if (const char *ev = getenv("STCSP_FRESH_INIT")) fresh_init = atoi(ev) != 0;
     if (const char *ev = getenv("STCSP_SPLIT_WIDE")) split_mode = atoi(ev);  // tuning / A-B: 0 keeps wide conditionals interpreted
     N = p->n_vars;
     K = p->prefix_k;
@@ -1075,6 +1076,12 @@ int SetManager::compile(FlatProgram &out) {
         out.items.insert(out.items.end(), small_items.begin(), small_items.end());
         out.items.insert(out.items.end(), wave_items.begin(), wave_items.end());
         sd.itemrows_off = (int32_t)out.itemrows.size();
+        // A set without `first` / `@` constraints says the same about EVERY state under it, so what its constraints make of the
+        // initial domains is worked out once (engine.hip fresh_init) and the new time point of a fresh state starts from that:
+        // its point items have no work until an arc from the point before changes one of their words (the closure marks them).
+        bool own_init = fresh_init && W == 1 && sets.size() * (size_t)N <= 4096 && s.first_vars.empty();
+        for (const HostCon &c : pcons) own_init = own_init && !c.has_first && c.type != CT_AT;
+        out.set_fresh_init.push_back(own_init ? 1 : 0);
         // rows [0, N*K): the items that read block word (p, v); row N*K: the items with work in a FRESH state under the same set
         // (dirty seed N*K + 1, dev_propagate.hpp process_node) -- those that read the new time point K-1, until checks (their
         // expire bits change with the state) and constraints with a `first` (enforced at point 0 only, which they now see for
@@ -1091,7 +1098,7 @@ int SetManager::compile(FlatProgram &out) {
             } else {
                 const ConDesc &cd = out.cons[it.con];
                 for (int j = 0; j < cd.scope_len; j++) mark(it.point * N + out.scope[cd.scope_off + j]);
-                fresh = it.point == K - 1 || cd.npoints < K;
+                fresh = (it.point == K - 1 && !own_init) || cd.npoints < K;
             }
             if (fresh) mark(N * K);
         }

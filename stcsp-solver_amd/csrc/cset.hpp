@@ -76,6 +76,10 @@ struct FlatProgram {
                                     // their own, so that a few hundred words every sweep reads are staged in LDS even when the tuple
                                     // bitmaps in `tables` run to megabytes (digitinvader9: 268 words beside 4.9 MB)
     std::vector<int32_t> strides;
+    // Per set: 1 when a fresh state under the set may start its new time point from the set's own PROPAGATED initial domains (the
+    // engine works them out once per set: engine.hip fresh_init) -- the point items over the new point are then not dirty in a fresh
+    // state (dirty row N*K); all zero when the table of nsets x N words would not stay small.
+    std::vector<uint8_t> set_fresh_init;
     int max_stack = 1;
     int max_cw = 1;
     int max_iw = 1;
@@ -102,6 +106,7 @@ public:
     std::map<std::vector<int32_t>, std::vector<Tree *>> piece_cache;
     TreeArena piece_arena;
     int split_mode = 1;            // 0: never; 1: conditional constraints no bitmap can hold; 2: every conditional constraint that is not lane-revised
+    bool fresh_init = true;        // STCSP_FRESH_INIT=0: fresh states start from the plain initial domains, every item over the new point dirty
     int n_split = 0;               // constraints the last compile() replaced by their guarded branches
     int n_wide_conditional = 0;    // ... and conditional constraints over more than kWideConditional tuples it saw, split or not (engine: chain policy)
     long long split_target = 0;    // a branch at most this big is not split further (set by compile)

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         }
         NodeHdr hd;
         hd.h0 = hd.h1 = 0u;
-        hd.set = rfl(set);
+        hd.set = rfl(set >= 0 ? set : gw);  // (set < 0: block i under constraint set i, and no work counters -- engine.hip fresh_init)
         hd.seed = 0u;
         hd.expire = rflu(expire);
         BranchOut bo;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, (DR <= 2 ? 4 : 3)) void k_probe(const Ctx *__r
         }
         if (lane == 0) outcome[gw] = oc;
     }
-    flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
+    if (set >= 0) flush_env<DR>(c, env, blockIdx.x * 4 + wib, lane);
 }
 
 // ------------------------------------------------------------------ commit

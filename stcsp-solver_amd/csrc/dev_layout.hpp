@@ -117,6 +117,7 @@ struct ImgOff {
     int sets, cons, scope, strides, items, sweep, nextpart, itemrows, tables, var_lb, var_init, sig_vars, until_y, firstvars, trans, transvals,
         arr_off, code, stables, fstrides, words;  // stables: row tables of the lane-revised items (FlatProgram::stables)
     int hot_words;  // the image's first hot_words words are the sections every node touches (see upload_program)
+    int init_stride;  // var_init holds one row of N words per constraint set (N) or one row for all of them (0): the domains a fresh time point starts from
 };
 
 struct Ctx {

@@ -1650,7 +1650,7 @@ __device__ int process_node(const Ctx &c, const Img<L> &P, int lane, int *lds_va
         uint32_t nb = 0;
         if (idx < c.NK) {
             int p = idx / c.N, v = idx - p * c.N;
-            nb = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + v);
+            nb = (p + 1 < c.K) ? shifted : (uint32_t)P.v(c.o.var_init + next_set * c.o.init_stride + v);
         }
         lo.nblk[q] = nb;
     }

@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <type_traits>
@@ -267,6 +268,20 @@ struct stcsp_engine {
         std::vector<uint32_t> init((size_t)ctx.N * mgr.W);  // chunk-major: init[c * N + v]
         for (int c = 0; c < mgr.W; c++)
             for (int v = 0; v < ctx.N; v++) init[(size_t)c * ctx.N + v] = init_chunk(v, c);
+        // one row per constraint set when some set starts its fresh time points from its own propagated initial domains
+        // (FlatProgram::set_fresh_init; the rows are filled in by fresh_init() once the program runs, known ones are kept)
+        own_init_rows = false;
+        for (uint8_t f : prog.set_fresh_init) own_init_rows = own_init_rows || f;
+        if (own_init_rows) {
+            const std::vector<uint32_t> plain = init;
+            init.resize((size_t)ctx.N * prog.sets.size());
+            for (size_t si = 0; si < prog.sets.size(); si++) {
+                auto known = fresh_rows.find(mgr.sets[si]->tag);
+                const std::vector<uint32_t> &row = (prog.set_fresh_init[si] && known != fresh_rows.end()) ? known->second : plain;
+                std::copy(row.begin(), row.end(), init.begin() + si * ctx.N);
+            }
+        }
+        o.init_stride = own_init_rows ? ctx.N : 0;
         // Sections in the order of how much a node needs them: what every node reads (the lane-per-item sweep
         // reads `sweep` and `itemrows` with per-lane addresses), then what wavefront revisions read before they can
         // start (item records, scopes, strides, the bytecode: small, and every read of them sits in a dependent
@@ -683,7 +698,7 @@ struct stcsp_engine {
         HIPCHK(d_cand.alloc((size_t)opt.world * R * cand_cap * ctx.CS));
         if (sharded) HIPCHK(d_pack.alloc((size_t)R * cand_cap * ctx.CS));
         sync_ctx();
-        return STCSP_OK;
+        return fresh_init();
     }
 
     int alloc_table(uint32_t slots) {
@@ -1189,6 +1204,56 @@ struct stcsp_engine {
         });
     }
 
+    // The domains a fresh time point starts from, per constraint set (FlatProgram::set_fresh_init): the set's constraints applied
+    // to the plain initial domains at every point (k_probe: one block per set, every until constraint taken as expired), of which
+    // the last point's words are kept. Sound for every state under the set: its earlier points hold subsets of the initial
+    // domains, so whatever the arcs from them leave of the new point is a subset of what they leave here. Run after every
+    // upload of a program with sets that have no row yet (creation, a translation stop, a set import).
+    bool own_init_rows = false;
+    std::map<int32_t, std::vector<uint32_t>> fresh_rows;  // set tag -> its row
+    int fresh_init() {
+        if (!own_init_rows || mgr.W != 1) return STCSP_OK;
+        std::vector<int> todo;
+        for (size_t si = 0; si < prog.sets.size(); si++)
+            if (prog.set_fresh_init[si] && !fresh_rows.count(mgr.sets[si]->tag)) todo.push_back((int)si);
+        if (todo.empty()) return STCSP_OK;
+        const int N = ctx.N, K = ctx.K, ns = (int)prog.sets.size();
+        bool all_fixed = true;
+        for (int v = 0; v < N; v++) all_fixed = all_fixed && mgr.lb[v] == mgr.ub[v];
+        std::vector<uint32_t> blocks((size_t)ns * ctx.NK);
+        for (int si = 0; si < ns; si++)
+            for (int p = 0; p < K; p++)
+                for (int v = 0; v < N; v++) blocks[(size_t)si * ctx.NK + (size_t)p * N + v] = init_chunk(v, 0);
+        std::vector<int> outcome((size_t)ns, (int)OC_FAIL);
+        if (!all_fixed) {  // (a block of singletons is a leaf: nothing to gain, and its transition look-up is not for here)
+            HIPCHK(hipSetDevice(device));
+            int rc = flush_ctx();
+            if (rc != STCSP_OK) return rc;
+            DevBuf<uint32_t> d_blk;
+            DevBuf<int> d_out;
+            HIPCHK(d_blk.upload(blocks));
+            HIPCHK(d_out.alloc((size_t)ns));
+            const unsigned grid = (unsigned)std::min<int64_t>((ns + 3) / 4, max_blocks);
+            switch (DR) {
+                case 1: launch_probe<1>(grid, d_blk.p, ns, -1, 0xffffffffu, d_out.p); break;
+                case 2: launch_probe<2>(grid, d_blk.p, ns, -1, 0xffffffffu, d_out.p); break;
+                default: launch_probe<4>(grid, d_blk.p, ns, -1, 0xffffffffu, d_out.p); break;
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(blocks.data(), d_blk.p, blocks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(outcome.data(), d_out.p, (size_t)ns * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        for (int si : todo) {
+            std::vector<uint32_t> row((size_t)N);
+            for (int v = 0; v < N; v++) row[v] = outcome[si] == (int)OC_FAIL ? init_chunk(v, 0) : blocks[(size_t)si * ctx.NK + (size_t)(K - 1) * N + v];
+            HIPCHK(hipMemcpyAsync(d_img.p + ctx.o.var_init + (size_t)si * N, row.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));  // (row is a local)
+            fresh_rows[mgr.sets[si]->tag] = std::move(row);
+        }
+        return STCSP_OK;
+    }
+
     // stcsp_engine_propagate: process_node on caller-provided blocks (k_probe)
     template <int DRT>
     void launch_probe(unsigned grid, uint32_t *blocks, int n, int set, uint32_t expire, int *outcome) {
@@ -1417,7 +1482,8 @@ struct stcsp_engine {
         }
         uint32_t zero = 0;
         HIPCHK(hipMemcpyAsync(d_ctl.p + L.misc0 + MISC_NMISS * CST, &zero, sizeof zero, hipMemcpyHostToDevice, stream));
-        return upload_program();
+        const int rcu = upload_program();
+        return rcu != STCSP_OK ? rcu : fresh_init();
     }
 
     // Enqueue bursts of rounds until the device plan stops: done, outbox full (sharded), or
@@ -2380,7 +2446,10 @@ int stcsp_engine_sets_import(stcsp_engine *e, const int32_t *words, int64_t n) {
         if (rc < 0) return e->fail(rc, "%s", e->mgr.error.c_str());
         pos += len;
     }
-    if (e->mgr.sets.size() != before) return e->upload_program();
+    if (e->mgr.sets.size() != before) {
+        const int rcu = e->upload_program();
+        return rcu != STCSP_OK ? rcu : e->fresh_init();
+    }
     return STCSP_OK;
 }
 
