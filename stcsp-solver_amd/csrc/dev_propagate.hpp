@@ -529,6 +529,47 @@ __device__ bool revise_point(const Ctx &c, const Img<L> &G, WaveEnv<DR> &S, cons
     constexpr int kOdoAhead = 4;
     if (use_bitmap && highmask) {
         bool wrapped = false;
+        // Diagonal first: before the odometer counts through the product, the tuples in which EVERY high variable takes its d-th
+        // value (d = 0 .. 3; the last one where a domain is shorter) are looked at. A loose constraint -- digitinvader's
+        // `next D7 == if GAMEOVER then -1 else if MISS or A0 or ... or A7 then D8 else D7` with the A's still open -- shows a support
+        // for every value of every variable within two of them, where the odometer needs half its range (2^(h-1) + 1 steps for
+        // h boolean high variables: 17 of 32) before the last variable has shown its second value; the "everything supported
+        // already" exit then ends the revision. Nothing else changes: when the diagonal does not settle it, the odometer
+        // enumerates the whole product as before (supports do not depend on the order they are found in).
+        if constexpr (kOdoAhead == 4) {
+            uint32_t wlo[4], whi[4];
+            int cb[4], shv[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int dig = min(d, n - 1);
+                cb[d] = is_high ? select_kth_fast(D, dig) : curbit;
+                int bit = lane_part + base_sum;
+                for (unsigned long long hm = highmask; hm; hm &= hm - 1) {
+                    const int j = __ffsll((long long)hm) - 1;
+                    bit += (int)rdlane((uint32_t)cb[d], j) * (int)rdlane((uint32_t)mystride, j);
+                }
+                const int tw = c.o.tables + C.bitmap_off + (bit >> 5), sh = bit & 31;
+                shv[d] = sh;
+                wlo[d] = active ? (uint32_t)G.vc(tw) : 0u;
+                whi[d] = (active && sh + (31 - __clz((int)D0)) >= 32) ? (uint32_t)G.vc(tw + 1) : 0u;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t sup0 = (uint32_t)((((unsigned long long)whi[d] << 32) | wlo[d]) >> shv[d]) & D0;
+                acc0 |= sup0;
+                const bool sat = active && sup0 != 0;
+                if (__ballot(sat)) {
+                    any_sat = true;
+                    satany = satany || sat;
+                    if (is_high) hs |= 1u << cb[d];
+                }
+            }
+            S.n_evals += (unsigned)(Plow * 4);
+#ifdef STCSP_PHASES
+            ws.rv_blocks += 4u;
+#endif
+            wrapped = __ballot((active && !satany) || (is_high && hs != D)) == 0 && wave_or32(acc0) == D0;  // settled: no odometer
+        }
         for (unsigned long long step = 0; !wrapped; step += kOdoAhead) {
             const unsigned long long t_b1 = PHASE_NOW();
             (void)t_b1;
