@@ -1086,7 +1086,8 @@ int SetManager::compile(FlatProgram &out) {
         // (dirty seed N*K + 1, dev_propagate.hpp process_node) -- those that read the new time point K-1, until checks (their
         // expire bits change with the state) and constraints with a `first` (enforced at point 0 only, which they now see for
         // the first time); every other item saw the same domains one point later in the leaf the state comes from
-        out.itemrows.resize(out.itemrows.size() + ((size_t)N * K + 1) * sd.iw, 0u);
+        // ... row N*K + 1: the wavefront-revised items revise_batch can take (a tuple bitmap, at most kBatchArity scope variables)
+        out.itemrows.resize(out.itemrows.size() + ((size_t)N * K + 2) * sd.iw, 0u);
         for (int i = 0; i < sd.nitems; i++) {
             const ItemDesc &it = out.items[sd.item_begin + i];
             auto mark = [&](int word) { out.itemrows[sd.itemrows_off + (size_t)word * sd.iw + i / 32] |= 1u << (i % 32); };
@@ -1101,6 +1102,7 @@ int SetManager::compile(FlatProgram &out) {
                 fresh = (it.point == K - 1 && !own_init) || cd.npoints < K;
             }
             if (fresh) mark(N * K);
+            if (i >= sd.nsmall && it.type == IT_WAVE && it.idx[1] >= 0 && it.arity <= kBatchArity) mark(N * K + 1);
         }
         out.sets.push_back(sd);
     }

@@ -938,7 +938,7 @@ __device__ bool close_next(const Ctx &c, const Img<L> &P, const WaveEnv<DR> &S, 
 // Items with more than 64 tuples / kMaxLowVars open variables, or without a bitmap, are left to revise_point.
 // Returns -1 on a wipe-out, 0 when the FIRST dirty item is not batchable (the caller revises it alone), else the
 // number of items dealt with. `scr`: kBatchItems records of kBatchRec words; `clr`: 64 words.
-constexpr int kBatchItems = 16, kBatchRec = 24, kBatchArity = 16, kBatchTuples = 256;  // tuples of one batch: looked at 64 at a time
+constexpr int kBatchItems = 16, kBatchRec = 24, kBatchTuples = 256;  // tuples of one batch: looked at 64 at a time
 static_assert(kBatchItems * kBatchRec <= kMaxLowVars * 64, "the batch records live in the lane-value scratch of the general revision");
 // record of one batch item (16-byte aligned parts, so that a tuple lane fetches it with four wide LDS reads)
 enum { BR_NOPEN = 0, BR_BASE = 1, BR_D0 = 2, BR_BITMAP = 3, BR_WPACK = 4 /* 2 words: block word of open variable q in byte q */, BR_SUP0 = 6,
@@ -948,24 +948,9 @@ static_assert(kMaxLowVars <= 6, "batch record layout");
 // at most kBatchArity variables (the only ones revise_batch can take); worked out once per constraint set
 template <int DR, int L>
 __device__ __forceinline__ void load_bmmask(const Ctx &c, const Img<L> &P, int lane, WaveEnv<DR> &E) {
-    uint32_t m = 0;
-    if (lane < E.iw) {
-        for (int b0 = 0; b0 < 32; b0 += 4) {
-            int bm[4], ar[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int item = lane * 32 + b0 + i;
-                const bool in = item >= E.nsmall && item < E.nitems;
-                const int ib = E.items_abs + item * (int)(sizeof(ItemDesc) / 4);
-                bm[i] = in ? P.v(ib + (int)(offsetof(ItemDesc, idx) / 4) + 1) : -1;
-                ar[i] = in ? P.v(ib + (int)(offsetof(ItemDesc, arity) / 4)) : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) m |= ((bm[i] >= 0 && ar[i] <= kBatchArity) ? 1u : 0u) << (b0 + i);
-        }
-    }
-    STCSP_REJOIN();
-    E.bmmask = m;
+    // (row N*K + 1 of the set's dirty rows, laid down by the compiler: cset.cpp compile -- round 3 derived it here from the item
+    // records, 32 dependent reads per lane at the start of every slot's first node)
+    E.bmmask = lane < E.iw ? (uint32_t)P.v(E.rows_abs + (c.N * c.K + 1) * E.iw + lane) : 0u;
 }
 // reductions over the rows of 16 lanes (every lane ends up with its row's result): DPP rotations, no LDS
 __device__ __forceinline__ int row_ror(int v, int by) {

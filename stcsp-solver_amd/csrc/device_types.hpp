@@ -39,6 +39,7 @@ constexpr long long kBitmapMaxBits = 1ll << 22;  // largest tuple bitmap the HOS
 constexpr long long kDirectTransMax = 1ll << 22;  // entries of one constraint set's direct transition table (4 B each)
 constexpr long long kDirectTransTotalMax = 1ll << 26;  // ... and of all the tables of one program (256 MB)
 constexpr long long kWideConditional = 1ll << 20;  // a conditional constraint over more tuples than this marks a program whose search is shallow and bushy (engine.hip: chain policy)
+constexpr int kBatchArity = 16;             // scope variables of an item revise_batch can take (one row of 16 lanes scans a scope)
 constexpr int kTabulateMaxStack = 32;        // operand-stack entries of k_tabulate's per-thread interpreter (deeper programs are not tabulated on the device)
 constexpr long long kBitmapMaxBitsDevice = 1ll << 28;  // ... and the largest one at all: bigger ones up to here are tabulated on the device
 

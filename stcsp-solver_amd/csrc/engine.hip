@@ -1247,10 +1247,16 @@ struct stcsp_engine {
         for (int si : todo) {
             std::vector<uint32_t> row((size_t)N);
             for (int v = 0; v < N; v++) row[v] = outcome[si] == (int)OC_FAIL ? init_chunk(v, 0) : blocks[(size_t)si * ctx.NK + (size_t)(K - 1) * N + v];
-            HIPCHK(hipMemcpyAsync(d_img.p + ctx.o.var_init + (size_t)si * N, row.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));  // (row is a local)
             fresh_rows[mgr.sets[si]->tag] = std::move(row);
         }
+        // the whole table (at most 4,096 words) in one copy: plain rows for the sets that keep them, as upload_program laid them out
+        std::vector<uint32_t> table((size_t)ns * N);
+        for (int si = 0; si < ns; si++) {
+            auto known = prog.set_fresh_init[si] ? fresh_rows.find(mgr.sets[si]->tag) : fresh_rows.end();
+            for (int v = 0; v < N; v++) table[(size_t)si * N + v] = known != fresh_rows.end() ? known->second[v] : init_chunk(v, 0);
+        }
+        HIPCHK(hipMemcpyAsync(d_img.p + ctx.o.var_init, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));  // (table is a local)
         return STCSP_OK;
     }
 
